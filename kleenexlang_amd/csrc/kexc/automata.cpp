@@ -1,0 +1,496 @@
+// automata.cpp — reduced grammar → FST → streaming string transducer.
+//
+//   constructTransducer   src/KMC/SymbolicFST/Transducer.hs:57-107 (+ projectTransducer :114-133)
+//   determinize           src/KMC/Determinization.hs:38-257, src/KMC/TreeWriter.hs:30-119,
+//                         src/KMC/SymbolicFST.hs:229-241,298-312 (tests), Theories.hs:58-80
+//   optimizeSST           src/KMC/SymbolicSST.hs:180-331
+//
+// Besides the register form the reference produces, determinize() records for
+// every transition the *path form*: for each leaf of the target path tree, the
+// leaf of the source tree it extends and the output appended on the way.  The
+// concatenation of a root→leaf path never changes except by appending at the
+// leaf (LCP hoisting only moves atoms towards the root), so the program's
+// output is the concatenation of these per-step suffixes along the surviving
+// path — which is what the GPU engine evaluates.
+#include <algorithm>
+#include <deque>
+#include <functional>
+
+#include "kexc.h"
+
+namespace kexc {
+
+// ======================================================================= FST
+FST constructTransducer(const RProg& rp, int start) {
+  using Stack = std::vector<int>;
+  auto getDecl = [&](int i) -> const RTerm& {
+    auto it = rp.decls.find(i);
+    if (it == rp.decls.end()) throw CompileError("internal error: identifier without declaration: " + std::to_string(i));
+    return it->second;
+  };
+  // Transducer.hs:98-103 — contract RSeq heads and single-alternative RSum heads
+  std::function<Stack(Stack)> follow = [&](Stack st) -> Stack {
+    int guard = 0;
+    while (!st.empty()) {
+      const RTerm& d = getDecl(st[0]);
+      if (d.kind == RTerm::RSeq) { Stack n(d.ids); n.insert(n.end(), st.begin() + 1, st.end()); st = std::move(n); }
+      else if (d.kind == RTerm::RSum && d.ids.size() == 1) st[0] = d.ids[0];
+      else break;
+      if (++guard > 1000000 || st.size() > 100000) throw CompileError("grammar is not right-regular (unbounded continuation stack)");
+    }
+    return st;
+  };
+  struct Edge { Stack from; bool is_sym; ByteSet pred; bool copy; std::string out; Stack to; };
+  std::set<Stack> states, ws;
+  std::vector<Edge> edges;
+  ws.insert(Stack{start});
+  while (!ws.empty()) {
+    Stack q = *ws.begin(); ws.erase(ws.begin());
+    if (states.count(q)) continue;
+    states.insert(q);
+    if (states.size() > 2000000) throw CompileError("transducer too large (grammar not right-regular?)");
+    if (q.empty()) continue;
+    Stack rest(q.begin() + 1, q.end());
+    const RTerm& d = getDecl(q[0]);
+    switch (d.kind) {
+      case RTerm::RConst: {
+        if (d.c.kind != 0)  // Commands.hs:165-168
+          throw CompileError("Transducer contains action symbols - direct SST generation not supported");
+        Stack t = follow(rest); ws.insert(t);
+        edges.push_back({q, false, {}, false, std::string(1, char(d.c.arg)), t}); break;
+      }
+      case RTerm::RRead: {
+        Stack t = follow(rest); ws.insert(t);
+        edges.push_back({q, true, d.pred, d.copy, "", t}); break;
+      }
+      case RTerm::RSeq: {
+        Stack n(d.ids); n.insert(n.end(), rest.begin(), rest.end());
+        Stack t = follow(n); ws.insert(t);
+        edges.push_back({q, false, {}, false, "", t}); break;
+      }
+      case RTerm::RSum:
+        for (int j : d.ids) {  // alternative order = priority order
+          Stack n{j}; n.insert(n.end(), rest.begin(), rest.end());
+          Stack t = follow(n); ws.insert(t);
+          edges.push_back({q, false, {}, false, "", t});
+        }
+        break;
+    }
+  }
+  // enumerateStates (SymbolicFST.hs:314-326): number in Ord order of the stacks
+  std::map<Stack, int> id;
+  int n = 0;
+  for (auto& s : states) id[s] = n++;
+  FST f;
+  f.nstates = n; f.init = id[Stack{start}];
+  f.is_final.assign(n, 0);
+  if (id.count(Stack{})) f.is_final[id[Stack{}]] = 1;
+  f.eps.resize(n); f.sym.resize(n);
+  for (auto& e : edges) {
+    if (e.is_sym) f.sym[id[e.from]].push_back({e.pred, e.copy, id[e.to]});
+    else f.eps[id[e.from]].push_back({e.out, id[e.to]});
+  }
+  return f;
+}
+
+// =============================================================== path trees
+namespace {
+
+struct Tree {  // TreeWriter.hs:30-33; `tag` rides along with the leaf value
+  UpdateString out;
+  bool tip = true;
+  int st = 0, tag = -1;
+  std::vector<Tree> kids;
+};
+using MTree = std::optional<Tree>;
+
+void prepend(const UpdateString& w, Tree& t) { t.out.insert(t.out.begin(), w.begin(), w.end()); }
+
+// x >>= f on trees (TreeWriter.hs:78-92): leaves are visited left to right
+MTree bindTree(const Tree& t, const std::function<MTree(int, int)>& f) {
+  if (t.tip) {
+    MTree r = f(t.st, t.tag);
+    if (!r) return std::nullopt;
+    prepend(t.out, *r);
+    return r;
+  }
+  std::vector<Tree> ts;
+  for (auto& k : t.kids) { MTree r = bindTree(k, f); if (r) ts.push_back(std::move(*r)); }
+  if (ts.empty()) return std::nullopt;
+  if (ts.size() == 1) { prepend(t.out, ts[0]); return std::move(ts[0]); }
+  Tree r; r.tip = false; r.out = t.out; r.kids = std::move(ts);
+  return r;
+}
+
+// Determinization.hs:65-71 — hoist the longest common prefix of sibling outputs
+void reduceTree(Tree& t) {
+  if (t.tip) return;
+  for (auto& k : t.kids) reduceTree(k);
+  size_t n = t.kids[0].out.size();
+  for (auto& k : t.kids) n = std::min(n, k.out.size());
+  size_t l = 0;
+  for (; l < n; ++l) {
+    bool same = true;
+    for (size_t i = 1; i < t.kids.size() && same; ++i) same = t.kids[i].out[l] == t.kids[0].out[l];
+    if (!same) break;
+  }
+  if (l) {
+    t.out.insert(t.out.end(), t.kids[0].out.begin(), t.kids[0].out.begin() + l);
+    for (auto& k : t.kids) k.out.erase(k.out.begin(), k.out.begin() + l);
+  }
+}
+
+Atom constAtom(const std::string& b) { Atom a; a.kind = Atom::CONST; a.bytes = b; return a; }
+Atom varAtom(int v) { Atom a; a.kind = Atom::VAR; a.var = v; return a; }
+Atom funcAtom(int f) { Atom a; a.kind = Atom::FUNC; a.func = f; return a; }
+
+struct Determinizer {
+  const FST& f;
+  explicit Determinizer(const FST& fst) : f(fst) {}
+
+  // Determinization.hs:82-93 — ε-closure below one leaf; `vis` is shared by the whole tree walk
+  MTree genclosure(int q, int tag, std::set<int>& vis) {
+    const auto& es = f.eps[q];
+    if (es.empty()) { Tree t; t.st = q; t.tag = tag; return t; }
+    std::vector<Tree> ts;
+    for (auto& e : es) {
+      if (vis.count(e.to)) continue;   // visit: a state reached a second time is dropped
+      vis.insert(e.to);
+      MTree sub = genclosure(e.to, tag, vis);
+      if (!sub) continue;
+      prepend({constAtom(e.out)}, *sub);
+      ts.push_back(std::move(*sub));
+    }
+    if (ts.empty()) return std::nullopt;
+    if (ts.size() == 1) return std::move(ts[0]);
+    Tree r; r.tip = false; r.kids = std::move(ts);
+    return r;
+  }
+  MTree closeTree(const Tree& t) {
+    std::set<int> vis;
+    MTree r = bindTree(t, [&](int q, int tag) { return genclosure(q, tag, vis); });
+    if (r) reduceTree(*r);
+    return r;
+  }
+  MTree consumeTree(const Tree& t, const ByteSet& p) {  // Determinization.hs:108-114
+    std::set<int> vis;
+    MTree r = bindTree(t, [&](int q, int tag) -> MTree {
+      const FST::Sym* hit = nullptr;
+      for (auto& e : f.sym[q]) if (p.subsetOf(e.pred)) {
+        if (hit) throw CompileError("Stepping for FSTs with read-fanout greater than one is not supported yet");
+        hit = &e;
+      }
+      if (!hit) return std::nullopt;
+      if (vis.count(hit->to)) return std::nullopt;
+      vis.insert(hit->to);
+      Tree n; n.st = hit->to; n.tag = tag; n.out = {funcAtom(hit->copy ? 0 : 1)};
+      return n;
+    });
+    if (r) reduceTree(*r);
+    return r;
+  }
+  MTree eofTree(const Tree& t) {  // Determinization.hs:116-118,144-145
+    std::set<int> vis;
+    MTree r = bindTree(t, [&](int q, int tag) -> MTree {
+      if (!f.is_final[q] || vis.count(q)) return std::nullopt;
+      vis.insert(q);
+      Tree n; n.st = q; n.tag = tag; return n;
+    });
+    if (r) reduceTree(*r);
+    return r;
+  }
+};
+
+// Theories.hs:58-80 — coarsest partition of the union refining every predicate
+std::vector<ByteSet> coarsestPartition(const std::vector<ByteSet>& preds) {
+  std::map<std::vector<bool>, ByteSet> blocks;
+  for (int b = 0; b < 256; ++b) {
+    std::vector<bool> sig(preds.size());
+    bool any = false;
+    for (size_t i = 0; i < preds.size(); ++i) { sig[i] = preds[i].has(b); any = any || sig[i]; }
+    if (any) blocks[sig].add(b);
+  }
+  std::vector<ByteSet> out;
+  for (auto& kv : blocks) out.push_back(kv.second);
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+void leavesOf(const Tree& t, std::vector<const Tree*>& out) {
+  if (t.tip) { out.push_back(&t); return; }
+  for (auto& k : t.kids) leavesOf(k, out);
+}
+void tagLeaves(Tree& t, int& n) {
+  if (t.tip) { t.tag = n++; return; }
+  for (auto& k : t.kids) tagLeaves(k, n);
+}
+
+// state identity = tree shape + leaf FST states (register names are positional)
+void shapeKey(const Tree& t, std::string& k) {
+  if (t.tip) { k += "L" + std::to_string(t.st) + ";"; return; }
+  k += "(";
+  for (auto& c : t.kids) shapeKey(c, k);
+  k += ")";
+}
+
+}  // namespace
+
+SST determinize(const FST& f) {
+  Determinizer D(f);
+  std::map<std::vector<int>, int> varIds;          // Var [Int] (reversed path) → register id
+  auto varOf = [&](const std::vector<int>& path) {
+    auto it = varIds.find(path);
+    if (it != varIds.end()) return it->second;
+    int id = (int)varIds.size(); varIds[path] = id; return id;
+  };
+  varOf({});                                       // root = designated output register 0
+
+  // abstract (Determinization.hs:165-177): name nodes by position; returns the state skeleton
+  std::function<void(const Tree&, std::vector<int>&, std::map<int, UpdateString>*, Tree&)> abstractT =
+      [&](const Tree& t, std::vector<int>& pos, std::map<int, UpdateString>* kappa, Tree& skel) {
+        int v = varOf(pos);
+        if (kappa) (*kappa)[v] = t.out;
+        skel.out = {varAtom(v)};
+        skel.tip = t.tip; skel.st = t.st; skel.tag = -1;
+        skel.kids.clear();
+        if (!t.tip) {
+          skel.kids.resize(t.kids.size());
+          for (size_t m = 0; m < t.kids.size(); ++m) {
+            pos.insert(pos.begin(), (int)m);       // Var (m:v)
+            abstractT(t.kids[m], pos, kappa, skel.kids[m]);
+            pos.erase(pos.begin());
+          }
+        }
+      };
+
+  SST sst;
+  std::map<std::string, int> ids;
+  std::vector<Tree> skels;                         // abstracted tree of every SST state (outputs = own VAR)
+  std::deque<int> work;
+  auto intern = [&](const Tree& skel) {
+    std::string k; shapeKey(skel, k);
+    auto it = ids.find(k);
+    if (it != ids.end()) return it->second;
+    int id = (int)skels.size();
+    ids[k] = id; skels.push_back(skel); sst.states.emplace_back(); work.push_back(id);
+    if (skels.size() > 60000) throw CompileError("SST has more than 60000 states");
+    return id;
+  };
+  {
+    Tree t0; t0.st = f.init; t0.out = {varAtom(0)};
+    sst.init = intern(t0);
+  }
+  while (!work.empty()) {
+    int sid = work.front(); work.pop_front();
+    // closureAbstractTree (Determinization.hs:120-130); identity except for the initial state
+    MTree tcl = D.closeTree(skels[sid]);
+    if (!tcl) continue;                            // no live path: dead state
+    int nl = 0; tagLeaves(*tcl, nl);
+    std::vector<const Tree*> leaves; leavesOf(*tcl, leaves);
+    sst.states[sid].nleaves = nl;
+    if (sid == sst.init) {                         // path form of the initial closure
+      std::function<void(const Tree&, std::string)> walk = [&](const Tree& t, std::string acc) {
+        for (auto& a : t.out) if (a.kind == Atom::CONST) acc += a.bytes;
+        if (t.tip) { sst.init_path.push_back(acc); return; }
+        for (auto& k : t.kids) walk(k, acc);
+      };
+      walk(*tcl, "");
+    }
+    // final output (Determinization.hs:250)
+    if (MTree e = D.eofTree(*tcl); e && e->tip) {
+      sst.states[sid].is_final = true;
+      sst.states[sid].final_upd = e->out;
+      sst.states[sid].final_leaf = e->tag;
+    }
+    // tests: one per block of the coarsest partition of the leaves' predicates (--la=false)
+    std::set<ByteSet> pset;
+    for (auto* l : leaves) for (auto& e : f.sym[l->st]) pset.insert(e.pred);
+    std::vector<ByteSet> preds(pset.begin(), pset.end());
+    for (const ByteSet& p : coarsestPartition(preds)) {
+      // consumeTreeMany (Determinization.hs:213-228): close → consume → close
+      MTree a = D.closeTree(*tcl); if (!a) continue;
+      MTree b = D.consumeTree(*a, p); if (!b) continue;
+      MTree c = D.closeTree(*b); if (!c) continue;
+      SSTEdge edge; edge.pred = p;
+      // path form: per leaf of the new tree, origin leaf + the atoms after the VAR prefix
+      std::function<void(const Tree&, UpdateString)> walk = [&](const Tree& t, UpdateString acc) {
+        acc.insert(acc.end(), t.out.begin(), t.out.end());
+        if (!t.tip) { for (auto& k : t.kids) walk(k, acc); return; }
+        PathStep ps{t.tag, false, ""};
+        bool seen_new = false;
+        for (auto& at : acc) {
+          if (at.kind == Atom::VAR) { if (seen_new) throw CompileError("internal: register after new output on a path"); continue; }
+          seen_new = true;
+          if (at.kind == Atom::FUNC) {
+            if (!ps.bytes.empty() || ps.copy) throw CompileError("internal: symbol function not first on a path");
+            ps.copy = at.func == 0;
+          } else ps.bytes += at.bytes;
+        }
+        edge.path.push_back(ps);
+      };
+      if (sid == sst.init) {
+        // the initial tree is the only one that is not already closed: its closure output is
+        // accounted for in init_path, so measure the step against the closed tree alone
+        Tree marked = *tcl;
+        std::function<void(Tree&)> mark = [&](Tree& t) { t.out = {varAtom(-1)}; for (auto& k : t.kids) mark(k); };
+        mark(marked);
+        MTree a2 = D.closeTree(marked);
+        MTree b2 = a2 ? D.consumeTree(*a2, p) : std::nullopt;
+        MTree c2 = b2 ? D.closeTree(*b2) : std::nullopt;
+        if (!c2) throw CompileError("internal: path form diverges from register form");
+        walk(*c2, {});
+      } else walk(*c, {});
+      // register form: abstract, specialize, normalize (Determinization.hs:165-204, SymbolicSST.hs:109-120)
+      Tree skel; std::vector<int> pos; std::map<int, UpdateString> kappa;
+      abstractT(*c, pos, &kappa, skel);
+      bool single = p.size() == 1;
+      for (auto& kv : kappa) {
+        UpdateString norm;
+        for (auto at : kv.second) {
+          if (at.kind == Atom::FUNC) {
+            if (at.func == 1) at = constAtom("");
+            else if (single) at = constAtom(std::string(1, char(p.first())));
+          }
+          if (at.kind == Atom::CONST) {
+            if (at.bytes.empty()) continue;
+            if (!norm.empty() && norm.back().kind == Atom::CONST) { norm.back().bytes += at.bytes; continue; }
+          }
+          norm.push_back(at);
+        }
+        kv.second = std::move(norm);
+      }
+      edge.upd = std::move(kappa);
+      edge.to = intern(skel);
+      sst.states[sid].edges.push_back(std::move(edge));
+    }
+  }
+  for (auto& st : sst.states) {                    // normalize final updates
+    UpdateString norm;
+    for (auto& at : st.final_upd) {
+      if (at.kind == Atom::CONST) {
+        if (at.bytes.empty()) continue;
+        if (!norm.empty() && norm.back().kind == Atom::CONST) { norm.back().bytes += at.bytes; continue; }
+      }
+      norm.push_back(at);
+    }
+    st.final_upd = std::move(norm);
+  }
+  sst.nregs = (int)varIds.size();
+  return sst;
+}
+
+// ================================================================== optimize
+namespace {
+struct AbsVal { bool exact; std::string v; bool operator==(const AbsVal& o) const { return exact == o.exact && (!exact || v == o.v); } };
+using AbsValuation = std::map<int, AbsVal>;
+}  // namespace
+
+int optimizeSST(SST& s, int level) {  // SymbolicSST.hs:323-331
+  if (level <= 0) return 0;
+  bool weak = level < 3;
+  size_t n = s.states.size();
+  std::vector<AbsValuation> gamma(n);
+  // liftAbstractValuation (SymbolicSST.hs:210-219): nullopt = a referenced register has no info yet
+  auto lift = [](const AbsValuation& rho, const UpdateString& us) -> std::optional<AbsVal> {
+    AbsVal acc{true, ""};
+    // the reference folds from the right, but a missing register anywhere yields Nothing
+    for (auto& a : us) if (a.kind == Atom::VAR && !rho.count(a.var)) return std::nullopt;
+    for (auto& a : us) {
+      if (a.kind == Atom::VAR) { const AbsVal& x = rho.at(a.var); if (!x.exact) acc.exact = false; else acc.v += x.v; }
+      else if (a.kind == Atom::FUNC) { if (a.func == 0) acc.exact = false; }
+      else acc.v += a.bytes;
+    }
+    if (!acc.exact) acc.v.clear();
+    return acc;
+  };
+  // NB: `go` in the reference short-circuits on the first non-constant FuncA (→ Just Ambiguous even
+  // if a later register is missing).  Reproduce that order-sensitivity exactly:
+  auto liftExact = [&](const AbsValuation& rho, const UpdateString& us) -> std::optional<AbsVal> {
+    // evaluate right-to-left recursion of `go`: go (x:xs) combines x with go xs
+    std::function<std::optional<AbsVal>(size_t)> go = [&](size_t i) -> std::optional<AbsVal> {
+      if (i == us.size()) return AbsVal{true, ""};
+      const Atom& a = us[i];
+      if (a.kind == Atom::FUNC && a.func == 0) return AbsVal{false, ""};
+      if (a.kind == Atom::VAR) {
+        auto it = rho.find(a.var);
+        if (it == rho.end()) return std::nullopt;
+        auto rest = go(i + 1);
+        if (!rest) return std::nullopt;
+        if (!it->second.exact || !rest->exact) return AbsVal{false, ""};
+        return AbsVal{true, it->second.v + rest->v};
+      }
+      auto rest = go(i + 1);
+      if (!rest) return std::nullopt;
+      if (!rest->exact) return rest;
+      return AbsVal{true, (a.kind == Atom::CONST ? a.bytes : std::string()) + rest->v};
+    };
+    return go(0);
+  };
+  (void)lift;
+  auto lub = [](const AbsVal& a, const AbsVal& b) { return (a.exact && b.exact && a.v == b.v) ? a : AbsVal{false, ""}; };
+  auto lte = [](const AbsVal& a, const AbsVal& b) { return !b.exact || a == b; };
+
+  std::set<int> states;
+  for (size_t i = 0; i < n; ++i) states.insert((int)i);
+  int iters = 0;
+  while (!states.empty()) {  // abstractInterpretation (SymbolicSST.hs:286-299)
+    std::map<int, AbsValuation> contrib;
+    for (int r : states) {
+      const AbsValuation& rho_r = gamma[r];
+      for (auto& e : s.states[r].edges) {
+        AbsValuation rho2 = rho_r;  // M.union (mapMaybe lift kappa) rho
+        for (auto& kv : e.upd) {
+          AbsValuation base = rho_r;
+          if (weak) base[kv.first] = AbsVal{false, ""};
+          auto v = liftExact(base, kv.second);
+          if (v) rho2[kv.first] = *v;
+        }
+        auto it = contrib.find(e.to);
+        if (it == contrib.end()) contrib[e.to] = rho2;
+        else for (auto& kv : rho2) {  // M.unionWith lub
+          auto jt = it->second.find(kv.first);
+          if (jt == it->second.end()) it->second[kv.first] = kv.second; else jt->second = lub(jt->second, kv.second);
+        }
+      }
+    }
+    std::set<int> next;
+    for (auto& [st, rho2] : contrib) {
+      AbsValuation& cur = gamma[st];
+      bool sub = true;  // isSubmapOfBy lte rho2 cur
+      for (auto& kv : rho2) { auto jt = cur.find(kv.first); if (jt == cur.end() || !lte(kv.second, jt->second)) { sub = false; break; } }
+      if (sub) continue;
+      for (auto& kv : rho2) { auto jt = cur.find(kv.first); if (jt == cur.end()) cur[kv.first] = kv.second; else jt->second = lub(jt->second, kv.second); }
+      next.insert(st);
+    }
+    states.swap(next);
+    ++iters;
+  }
+  // applyAbstractEnvironment (SymbolicSST.hs:301-321)
+  auto apply = [](const AbsValuation& rho, const UpdateString& us) {
+    UpdateString out;
+    for (auto a : us) {
+      if (a.kind == Atom::VAR) { auto it = rho.find(a.var); if (it != rho.end() && it->second.exact) a = constAtom(it->second.v); }
+      if (a.kind == Atom::CONST) {
+        if (a.bytes.empty()) continue;
+        if (!out.empty() && out.back().kind == Atom::CONST) { out.back().bytes += a.bytes; continue; }
+      }
+      out.push_back(a);
+    }
+    return out;
+  };
+  for (size_t q = 0; q < n; ++q) {
+    for (auto& e : s.states[q].edges) {
+      std::map<int, UpdateString> k2;
+      for (auto& kv : e.upd) {
+        auto it = gamma[e.to].find(kv.first);
+        if (it != gamma[e.to].end() && it->second.exact) continue;  // statically known at the destination
+        k2[kv.first] = apply(gamma[q], kv.second);
+      }
+      e.upd = std::move(k2);
+    }
+    if (s.states[q].is_final) s.states[q].final_upd = apply(gamma[q], s.states[q].final_upd);
+  }
+  return iters;
+}
+
+}  // namespace kexc

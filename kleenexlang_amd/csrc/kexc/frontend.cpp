@@ -1,0 +1,554 @@
+// frontend.cpp — Kleenex surface syntax → reduced grammar (RProg).
+//
+// Follows the reference front end's *behaviour*:
+//   grammar / precedence / lexing   src/KMC/Kleenex/Parser.hs:34-222
+//   regex AST consumed              src/KMC/Kleenex/Desugaring.hs:73-118
+//   desugaring + hash-consing       src/KMC/Kleenex/Desugaring.hs:44-59,125-207
+// The regex-literal *syntax* lives in the un-vendored package
+// kmc-regexps-syntax @ 5c235fc057e25dffc1f5a3ca5a122ce1367ab594 (cabal.project:4-7);
+// the dialect accepted here is the one visible at the reference's call sites
+// (bench/kleenex/src/*.kex, test/test_compiled/src/*.kex): literals, `.`,
+// `[...]`/`[^...]` with ranges and escapes, `(...)`, `(?:...)`, `|`, `* + ?`
+// (+ lazy `*? +? ??`), `{n}`, `{n,}`, `{n,m}`.  Anything beyond is "parity
+// unpinned" (DESIGN.md).
+#include "kexc.h"
+
+#include <cctype>
+#include <cstring>
+#include <functional>
+
+namespace kexc {
+
+namespace {
+
+[[noreturn]] void fail(const std::string& srcname, const std::string& src, size_t pos, const std::string& msg) {
+  int line = 1, col = 1;
+  for (size_t i = 0; i < pos && i < src.size(); ++i) {
+    if (src[i] == '\n') { ++line; col = 1; } else ++col;
+  }
+  throw CompileError("\"" + srcname + "\" (line " + std::to_string(line) + ", column " + std::to_string(col) + "):\n" + msg);
+}
+
+void appendUtf8(std::string& out, unsigned cp) {
+  if (cp < 0x80) out += char(cp);
+  else if (cp < 0x800) { out += char(0xC0 | (cp >> 6)); out += char(0x80 | (cp & 0x3F)); }
+  else if (cp < 0x10000) { out += char(0xE0 | (cp >> 12)); out += char(0x80 | ((cp >> 6) & 0x3F)); out += char(0x80 | (cp & 0x3F)); }
+  else { out += char(0xF0 | (cp >> 18)); out += char(0x80 | ((cp >> 12) & 0x3F)); out += char(0x80 | ((cp >> 6) & 0x3F)); out += char(0x80 | (cp & 0x3F)); }
+}
+
+struct Parser {
+  const std::string& s;
+  const std::string& srcname;
+  size_t p = 0;
+  Parser(const std::string& src, const std::string& name) : s(src), srcname(name) {}
+
+  [[noreturn]] void err(const std::string& m) { fail(srcname, s, p, m); }
+  bool eof() const { return p >= s.size(); }
+  int peek(size_t k = 0) const { return p + k < s.size() ? (unsigned char)s[p + k] : -1; }
+  bool looking(const char* lit) const { return s.compare(p, strlen(lit), lit) == 0; }
+
+  // Parser.hs:34-39 — blanks, `// …` and `/* … */`
+  void ws() {
+    for (;;) {
+      if (!eof() && isspace(peek())) { ++p; continue; }
+      if (looking("//")) { while (!eof() && peek() != '\n') ++p; continue; }
+      if (looking("/*")) {
+        size_t e = s.find("*/", p + 2);
+        if (e == std::string::npos) err("unterminated comment");
+        p = e + 2; continue;
+      }
+      break;
+    }
+  }
+  bool symbol(const char* lit) { if (looking(lit)) { p += strlen(lit); ws(); return true; } return false; }
+
+  static bool isIdStart(int c) { return c >= 0 && (isalpha(c) || c >= 0x80); }
+  static bool isIdCont(int c) { return c >= 0 && (isalnum(c) || c == '_' || c == '-' || c >= 0x80); }
+  std::string rawIdent() {
+    if (!isIdStart(peek())) err("expecting nonterminal");
+    size_t b = p++;
+    while (isIdCont(peek())) ++p;
+    return s.substr(b, p - b);
+  }
+  int integer() {
+    if (!isdigit(peek())) err("expecting positive integer");
+    long v = 0;
+    while (isdigit(peek())) { v = v * 10 + (peek() - '0'); if (v > 1000000) err("integer too large"); ++p; }
+    return (int)v;
+  }
+
+  // Parser.hs:73-93
+  std::string stringConstant() {
+    if (peek() != '"') err("expecting string constant");
+    ++p;
+    std::string out;
+    for (;;) {
+      int c = peek();
+      if (c < 0) err("unterminated string constant");
+      if (c == '"') { ++p; break; }
+      if (c == '\\') {
+        ++p; int e = peek(); ++p;
+        switch (e) {
+          case '\\': out += '\\'; break; case '"': out += '"'; break; case 'n': out += '\n'; break;
+          case 't': out += '\t'; break; case 'v': out += '\v'; break; case 'r': out += '\r'; break;
+          case 'f': out += '\f'; break;
+          case 'x': {
+            int h1 = peek(), h2 = peek(1);
+            if (!isxdigit(h1) || !isxdigit(h2)) err("expecting escape sequence");
+            p += 2;
+            appendUtf8(out, (unsigned)strtol(std::string{char(h1), char(h2)}.c_str(), nullptr, 16));
+            break;
+          }
+          default: --p; err("expecting escape sequence");
+        }
+        continue;
+      }
+      out += char(c); ++p;
+    }
+    ws();
+    return out;
+  }
+
+  // ------------------------------------------------------------- regex literals
+  static RegexP mk(Regex::Kind k) { auto r = std::make_shared<Regex>(); r->kind = k; return r; }
+  static RegexP mk1(Regex::Kind k, RegexP a) { auto r = mk(k); r->a = a; return r; }
+  static RegexP mk2(Regex::Kind k, RegexP a, RegexP b) { auto r = mk(k); r->a = a; r->b = b; return r; }
+  static RegexP chrSeq(const std::string& bytes) {  // Desugaring.hs:77 (encodeChar per byte)
+    RegexP acc;
+    for (unsigned char b : bytes) { auto c = mk(Regex::Chr); c->chr = b; acc = acc ? mk2(Regex::Concat, acc, c) : c; }
+    return acc ? acc : mk(Regex::One);
+  }
+  unsigned utf8Decode() {  // one code point from the source text
+    unsigned c = (unsigned char)s[p++];
+    if (c < 0x80) return c;
+    int n = c >= 0xF0 ? 3 : c >= 0xE0 ? 2 : 1;
+    unsigned cp = c & (0x3F >> n);
+    while (n-- > 0 && !eof() && (peek() & 0xC0) == 0x80) cp = (cp << 6) | ((unsigned char)s[p++] & 0x3F);
+    return cp;
+  }
+  unsigned regexEscape() {  // after the backslash
+    int e = peek();
+    if (e < 0) err("dangling backslash in regex");
+    switch (e) {
+      case 'n': ++p; return '\n'; case 't': ++p; return '\t'; case 'r': ++p; return '\r';
+      case 'f': ++p; return '\f'; case 'v': ++p; return '\v'; case 'a': ++p; return 7;
+      case 'e': ++p; return 27; case '0': ++p; return 0;
+      case 'x': {
+        ++p;
+        if (peek() == '{') {
+          ++p; unsigned v = 0; while (isxdigit(peek())) { v = v * 16 + (unsigned)strtol(std::string(1, char(peek())).c_str(), nullptr, 16); ++p; }
+          if (peek() != '}') err("bad \\x{…} escape");
+          ++p;
+          return v;
+        }
+        int h1 = peek(), h2 = peek(1);
+        if (!isxdigit(h1) || !isxdigit(h2)) err("bad \\x escape");
+        p += 2;
+        return (unsigned)strtol(std::string{char(h1), char(h2)}.c_str(), nullptr, 16);
+      }
+      default:
+        if (isalnum(e)) err(std::string("unsupported regex escape \\") + char(e) + " (named sets not supported)");
+        return utf8Decode();
+    }
+  }
+  RegexP regexClass() {  // after '['
+    bool neg = false;
+    if (peek() == '^') { neg = true; ++p; }
+    ByteSet set;
+    bool first = true;
+    for (;;) {
+      int c = peek();
+      if (c < 0 || c == '/') err("unterminated character class");
+      if (c == ']' && !first) { ++p; break; }
+      first = false;
+      unsigned lo;
+      if (c == '\\') { ++p; lo = regexEscape(); } else lo = utf8Decode();
+      unsigned hi = lo;
+      if (peek() == '-' && peek(1) != ']' && peek(1) >= 0) {
+        ++p;
+        if (peek() == '\\') { ++p; hi = regexEscape(); } else hi = utf8Decode();
+      }
+      // Desugaring.hs:81-83: class bounds are code points squeezed into Word8
+      if (lo > 255 || hi > 255) err("character class member outside byte range");
+      if (hi < lo) err("invalid range in character class");
+      for (unsigned b = lo; b <= hi; ++b) set.add((int)b);
+    }
+    auto r = mk(Regex::Class);
+    r->cls = neg ? ~set : set;
+    return r;
+  }
+  RegexP regexAtom() {
+    int c = peek();
+    if (c == '.') { ++p; return mk(Regex::Dot); }
+    if (c == '[') { ++p; return regexClass(); }
+    if (c == '(') {
+      ++p;
+      if (looking("?:")) p += 2;
+      RegexP r = regexAlt();
+      if (peek() != ')') err("expecting ')' in regex");
+      ++p;
+      return mk1(Regex::Group, r);
+    }
+    if (c == '\\') { ++p; std::string b; appendUtf8(b, regexEscape()); return chrSeq(b); }
+    std::string b; appendUtf8(b, utf8Decode());
+    return chrSeq(b);
+  }
+  RegexP regexRepeat() {
+    RegexP r = regexAtom();
+    for (;;) {
+      int c = peek();
+      bool lazy = false;
+      if (c == '*' || c == '+' || c == '?') {
+        ++p;
+        if (peek() == '?') { lazy = true; ++p; }
+        Regex::Kind k = c == '*' ? (lazy ? Regex::LazyStar : Regex::Star)
+                       : c == '+' ? (lazy ? Regex::LazyPlus : Regex::Plus)
+                                  : (lazy ? Regex::LazyQuestion : Regex::Question);
+        r = mk1(k, r);
+      } else if (c == '{' && isdigit(peek(1))) {
+        ++p;
+        auto q = mk1(Regex::Range, r);
+        q->lo = integer();
+        if (peek() == ',') {
+          ++p;
+          if (isdigit(peek())) { q->hi = integer(); q->has_hi = true; if (q->hi < q->lo) err("invalid regex range"); }
+        } else { q->hi = q->lo; q->has_hi = true; }
+        if (peek() != '}') err("expecting '}' in regex range");
+        ++p;
+        if (peek() == '?') err("lazy ranges not supported");  // Desugaring.hs:118
+        r = q;
+      } else break;
+    }
+    return r;
+  }
+  RegexP regexConcat() {
+    RegexP acc;
+    while (!eof() && peek() != '/' && peek() != '|' && peek() != ')') {
+      RegexP r = regexRepeat();
+      acc = acc ? mk2(Regex::Concat, acc, r) : r;
+    }
+    return acc ? acc : mk(Regex::One);
+  }
+  RegexP regexAlt() {
+    RegexP l = regexConcat();
+    if (peek() == '|') { ++p; return mk2(Regex::Branch, l, regexAlt()); }
+    return l;
+  }
+  RegexP regexLiteral() {  // between the slashes; Parser.hs:204-206
+    if (peek() == '^') ++p;  // anchors are implicit for Kleenex terms
+    RegexP r = regexAlt();
+    if (peek() != '/') err("expecting '/' to close regex");
+    return r;
+  }
+
+  // ------------------------------------------------------------------- terms
+  static TermP tk(Term::Kind k) { auto t = std::make_shared<Term>(); t->kind = k; return t; }
+
+  bool atTermStart() {
+    int c = peek();
+    if (c < 0) return false;
+    if (c == '~' || c == '"' || c == '/' || c == '!' || c == '[' || c == '(' || c == '1') return true;
+    if (isIdStart(c)) {  // identifier not followed by ":=" (that starts the next declaration)
+      size_t save = p;
+      rawIdent();
+      bool redirect = peek() == '@';
+      ws();
+      bool isdecl = looking(":=");
+      p = save;
+      return redirect || !isdecl;
+    }
+    return false;
+  }
+
+  TermP atom() {
+    int c = peek();
+    if (c == '1') { ++p; ws(); return tk(Term::One); }
+    if (c == '"') { auto t = tk(Term::Constant); t->bytes = stringConstant(); return t; }
+    if (c == '/') {
+      ++p;
+      auto t = tk(Term::RE);
+      t->re = regexLiteral();
+      ++p; ws();
+      return t;
+    }
+    if (c == '!') {
+      ++p;
+      auto t = tk(Term::WriteReg);
+      if (!islower(peek())) err("expecting register");
+      t->name = rawIdent(); ws();
+      return t;
+    }
+    if (c == '[') {
+      ++p; ws();
+      auto t = tk(Term::UpdateReg);
+      if (!islower(peek())) err("expecting register");
+      t->name = rawIdent(); ws();
+      if (symbol("<-")) {}
+      else if (symbol("+=")) t->upd.push_back({true, t->name});
+      else err("expecting \"<-\" or \"+=\"");
+      size_t n0 = t->upd.size();
+      for (;;) {
+        if (peek() == '"') t->upd.push_back({false, stringConstant()});
+        else if (islower(peek())) { t->upd.push_back({true, rawIdent()}); ws(); }
+        else break;
+      }
+      if (t->upd.size() == n0) err("expecting register or string constant");
+      if (!symbol("]")) err("expecting \"]\"");
+      return t;
+    }
+    if (c == '(') {
+      ++p; ws();
+      TermP t = term();
+      if (!symbol(")")) err("expecting \")\"");
+      return t;
+    }
+    if (isIdStart(c)) {
+      auto t = tk(Term::Var);
+      t->name = rawIdent(); ws();
+      return t;
+    }
+    err("expecting term");
+  }
+
+  TermP prefixed() {  // Parser.hs:158-163
+    if (peek() == '~') { ++p; ws(); auto t = tk(Term::Suppress); t->a = prefixed(); return t; }
+    if (peek() >= 0 && islower(peek())) {
+      size_t save = p;
+      std::string r = rawIdent();
+      if (peek() == '@') { ++p; auto t = tk(Term::RedirectReg); t->name = r; t->a = prefixed(); return t; }
+      p = save;
+    }
+    return atom();
+  }
+
+  TermP postfixed() {  // Parser.hs:164-181
+    TermP t = prefixed();
+    for (;;) {
+      int c = peek();
+      if (c == '*') { ++p; ws(); auto n = tk(Term::Star); n->a = t; t = n; }
+      else if (c == '?') { ++p; ws(); auto n = tk(Term::Question); n->a = t; t = n; }
+      else if (c == '+') { ++p; ws(); auto n = tk(Term::Plus); n->a = t; t = n; }
+      else if (c == '<' && isdigit(peek(1))) {
+        ++p; ws(); auto n = tk(Term::Approx); n->k = integer(); ws(); n->a = t;
+        if (!symbol(">")) err("expecting \">\"");
+        t = n;
+      } else if (c == '{') {
+        ++p;
+        auto n = tk(Term::Range); n->a = t;
+        if (isdigit(peek())) n->lo = integer();
+        if (peek() == ',') { ++p; if (isdigit(peek())) n->hi = integer(); }
+        else { if (n->lo < 0) err("expecting positive integer"); n->hi = n->lo; }
+        if (!symbol("}")) err("expecting \"}\"");
+        t = n;
+      } else break;
+    }
+    return t;
+  }
+
+  TermP seq() {  // juxtaposition, right associative
+    TermP l = postfixed();
+    if (peek() != '|' && atTermStart()) { auto n = tk(Term::Seq); n->a = l; n->b = seq(); return n; }
+    return l;
+  }
+  TermP term() {  // `|`, right associative, loosest
+    TermP l = seq();
+    if (symbol("|")) { auto n = tk(Term::Sum); n->a = l; n->b = term(); return n; }
+    return l;
+  }
+
+  Prog prog() {  // Parser.hs:208-213
+    Prog pr;
+    ws();
+    if (symbol("start:")) {
+      do { pr.pipeline.push_back(rawIdent()); ws(); } while (symbol(">>"));
+    } else pr.pipeline.push_back("main");
+    while (!eof()) {
+      Decl d;
+      d.name = rawIdent(); ws();
+      if (!symbol(":=")) err("expecting \":=\"");
+      d.term = term();
+      pr.decls.push_back(d);
+    }
+    if (pr.decls.empty()) err("expecting nonterminal");
+    return pr;
+  }
+};
+
+}  // namespace
+
+Prog parseKleenex(const std::string& src, const std::string& srcname) {
+  Parser ps(src, srcname);
+  return ps.prog();
+}
+
+// ================================================================ desugaring
+bool RTerm::operator<(const RTerm& o) const {
+  if (kind != o.kind) return kind < o.kind;
+  switch (kind) {
+    case RConst: return c < o.c;
+    case RRead: if (!(pred == o.pred)) return pred < o.pred; return copy < o.copy;
+    default: return ids < o.ids;
+  }
+}
+
+namespace {
+
+struct Desugarer {
+  std::map<int, RTerm> decls;
+  std::map<RTerm, int> rev;
+  int fresh = 0;
+  std::map<std::pair<std::string, bool>, int> idents;
+  std::map<std::string, int> regs;
+  std::vector<std::string> regnames;
+
+  int insertDecl(int i, const RTerm& t) { decls[i] = t; rev[t] = i; return i; }
+  int decl(const RTerm& t) {  // Desugaring.hs:52-59 (hash-consing)
+    auto it = rev.find(t);
+    if (it != rev.end()) return it->second;
+    return insertDecl(fresh++, t);
+  }
+  static RTerm seqT(std::vector<int> ids) { RTerm t; t.kind = RTerm::RSeq; t.ids = std::move(ids); return t; }
+  static RTerm sumT(std::vector<int> ids) { RTerm t; t.kind = RTerm::RSum; t.ids = std::move(ids); return t; }
+  static RTerm readT(const ByteSet& p, bool copy) { RTerm t; t.kind = RTerm::RRead; t.pred = p; t.copy = copy; return t; }
+  static RTerm constT(RAct a) { RTerm t; t.kind = RTerm::RConst; t.c = a; return t; }
+  int reg(const std::string& n) {
+    auto it = regs.find(n);
+    if (it != regs.end()) return it->second;
+    int id = (int)regnames.size(); regs[n] = id; regnames.push_back(n); return id;
+  }
+
+  int star(int ie, bool lazy) {  // Desugaring.hs:84-93 / 135-139
+    int ieps = decl(seqT({}));
+    int i = fresh++;
+    int iloop = decl(seqT({ie, i}));
+    return insertDecl(i, lazy ? sumT({ieps, iloop}) : sumT({iloop, ieps}));
+  }
+
+  int re(bool out, const RegexP& e) {  // Desugaring.hs:70-118
+    switch (e->kind) {
+      case Regex::One: return decl(seqT({}));
+      case Regex::Dot: return decl(readT(ByteSet::universe(), out));
+      case Regex::Chr: return decl(seqT({decl(readT(ByteSet::single(e->chr), out))}));
+      case Regex::Group: return re(out, e->a);
+      case Regex::Concat: { int a = re(out, e->a), b = re(out, e->b); return decl(seqT({a, b})); }
+      case Regex::Branch: { int a = re(out, e->a), b = re(out, e->b); return decl(sumT({a, b})); }
+      case Regex::Class: return decl(readT(e->cls, out));
+      case Regex::Star: return star(re(out, e->a), false);
+      case Regex::LazyStar: return star(re(out, e->a), true);
+      case Regex::Plus: { int ie = re(out, e->a); int is = star(re(out, e->a), false); return decl(seqT({ie, is})); }
+      case Regex::LazyPlus: { int ie = re(out, e->a); int is = star(re(out, e->a), true); return decl(seqT({ie, is})); }
+      case Regex::Question: { int ie = re(out, e->a); int ieps = decl(seqT({})); return decl(sumT({ie, ieps})); }
+      case Regex::LazyQuestion: { int ie = re(out, e->a); int ieps = decl(seqT({})); return decl(sumT({ieps, ie})); }
+      case Regex::Range: {
+        int ie = re(out, e->a);
+        std::vector<int> ids(e->lo, ie);
+        if (!e->has_hi) { ids.push_back(star(re(out, e->a), false)); return decl(seqT(ids)); }
+        if (e->hi == e->lo) return decl(seqT(ids));
+        // Standard meaning e{n,m} = eⁿ (e?)^(m-n); see DESIGN.md "parity unpinned" for the
+        // reference's `replicate m'` (Desugaring.hs:106-115), which coincides on all
+        // reference vectors (n == 0 or n == m).
+        int ieps = decl(seqT({}));
+        int iq = decl(sumT({ie, ieps}));
+        for (int k = 0; k < e->hi - e->lo; ++k) ids.push_back(iq);
+        return decl(seqT(ids));
+      }
+      case Regex::Suppress: return re(false, e->a);
+    }
+    throw CompileError("internal: regex kind");
+  }
+
+  int term(bool out, const TermP& t) {  // Desugaring.hs:125-170
+    switch (t->kind) {
+      case Term::Var: {
+        auto it = idents.find({t->name, out});
+        if (it == idents.end()) throw CompileError("Undefined identifier: " + t->name);
+        return it->second;
+      }
+      case Term::Constant: {
+        std::vector<int> ids;
+        if (out) for (unsigned char b : t->bytes) ids.push_back(decl(constT({0, b})));
+        return decl(seqT(ids));
+      }
+      case Term::RE: return re(out, t->re);
+      case Term::Seq: {
+        std::vector<int> ids;
+        std::function<void(const TermP&)> flat = [&](const TermP& x) {
+          if (x->kind == Term::Seq) { flat(x->a); flat(x->b); } else ids.push_back(term(out, x)); };
+        flat(t);
+        return decl(seqT(ids));
+      }
+      case Term::Sum: {
+        std::vector<int> ids;
+        std::function<void(const TermP&)> flat = [&](const TermP& x) {
+          if (x->kind == Term::Sum) { flat(x->a); flat(x->b); } else ids.push_back(term(out, x)); };
+        flat(t);
+        return decl(sumT(ids));
+      }
+      case Term::Star: return star(term(out, t->a), false);
+      case Term::Plus: { int it = term(out, t->a); int is = star(term(out, t->a), false); return decl(seqT({it, is})); }
+      case Term::Question: { int it = term(out, t->a); int ieps = decl(seqT({})); return decl(sumT({it, ieps})); }
+      case Term::Approx: throw CompileError("approximate matching <k> is not supported by this compiler");
+      case Term::Range: {
+        int it = term(out, t->a);
+        int m = t->lo < 0 ? 0 : t->lo;
+        std::vector<int> ids(m, it);
+        if (t->hi < 0) { ids.push_back(star(term(out, t->a), false)); return decl(seqT(ids)); }
+        if (t->hi < m) throw CompileError("invalid range: {" + std::to_string(m) + "," + std::to_string(t->hi) + "}");
+        if (t->hi == m) return decl(seqT(ids));
+        int ieps = decl(seqT({}));
+        int iq = decl(sumT({it, ieps}));
+        for (int k = 0; k < t->hi - m; ++k) ids.push_back(iq);
+        return decl(seqT(ids));
+      }
+      case Term::Suppress: return term(false, t->a);
+      case Term::One: return decl(seqT({}));
+      case Term::UpdateReg: {
+        std::vector<int> ids{decl(constT({1, 0}))};
+        for (auto& a : t->upd) {
+          if (a.is_reg) ids.push_back(decl(constT({3, reg(a.s)})));
+          else for (unsigned char b : a.s) ids.push_back(decl(constT({0, b})));
+        }
+        ids.push_back(decl(constT({2, reg(t->name)})));
+        return decl(seqT(ids));
+      }
+      case Term::WriteReg: return decl(constT({3, reg(t->name)}));
+      case Term::RedirectReg: {
+        int it = term(out, t->a);
+        int ipush = decl(constT({1, 0})), ipop = decl(constT({2, reg(t->name)}));
+        return decl(seqT({ipush, it, ipop}));
+      }
+    }
+    throw CompileError("internal: term kind");
+  }
+};
+
+}  // namespace
+
+RProg desugar(const Prog& p) {  // Desugaring.hs:173-207
+  Desugarer d;
+  int n = 0;
+  for (auto& dc : p.decls) {
+    if (d.idents.count({dc.name, true})) throw CompileError("Multiple declarations of identifier: " + dc.name);
+    d.idents[{dc.name, true}] = n++;
+    d.idents[{dc.name, false}] = n++;
+  }
+  d.fresh = n + 1;
+  for (auto& dc : p.decls) {
+    int i = d.idents[{dc.name, true}], j = d.idents[{dc.name, false}];
+    int i2 = d.term(true, dc.term);
+    int j2 = d.term(false, dc.term);
+    d.insertDecl(i, Desugarer::seqT({i2}));
+    d.insertDecl(j, Desugarer::seqT({j2}));
+  }
+  RProg rp;
+  for (auto& id : p.pipeline) {
+    auto it = d.idents.find({id, true});
+    if (it == d.idents.end()) throw CompileError("identifier in pipeline with no declaration: " + id);
+    rp.pipeline.push_back(it->second);
+  }
+  rp.decls = std::move(d.decls);
+  rp.regnames = std::move(d.regnames);
+  return rp;
+}
+
+}  // namespace kexc

@@ -1,0 +1,134 @@
+// main.cpp — the `kexc` command line.
+//
+// Keeps the reference's outer CLI for the compile path (src/kexc.hs:12-50,
+// options src/KMC/Frontend/Options.hs:146-181):
+//     kexc compile [main opts] [compile opts] FILE.kex --out BIN
+// Flags may appear before or after the subcommand and after the positional
+// file; booleans accept `--quiet` or `--quiet=true`.  Exactly one positional
+// argument, else usage + exit 1 (kexc.hs:22-27).
+//
+// Back ends:
+//   --backend=hip (default)  BIN = the generic host driver `kxrun` with the KXP
+//                            blob appended; at run time it drives libkxhip.so
+//                            (stdin → HBM → HIP engine → stdout).
+//   --backend=c              reference-shaped C piped to `cc -O3 -xc -o BIN
+//                            "-D FLAG_WORDALIGNED" -` exactly as C.hs:556-568
+//                            does; needs --crt-dir (directory holding crt.c).
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <climits>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "kexc.h"
+
+using namespace kexc;
+
+static std::string selfDir() {
+  char buf[PATH_MAX];
+  ssize_t n = readlink("/proc/self/exe", buf, sizeof buf - 1);
+  if (n <= 0) return ".";
+  buf[n] = 0;
+  std::string s(buf);
+  return s.substr(0, s.rfind('/'));
+}
+
+static int usage() {
+  std::cout << "Usage: kexc compile [--quiet] [--opt N] [--la[=BOOL]] [--act[=BOOL]] [--copt N] [--cc CC]\n"
+               "                    [--backend=hip|c] [--crt-dir DIR] [--srcout FILE] [--blob FILE] FILE.kex --out BIN\n"
+               "Subcommands simulate / interpret / visualize of the reference are not part of this build.\n";
+  return 1;
+}
+
+static bool parseBool(const std::string& v) {
+  if (v == "true" || v == "True" || v == "1") return true;
+  if (v == "false" || v == "False" || v == "0") return false;
+  throw CompileError("bad boolean value: " + v);
+}
+
+int main(int argc, char** argv) {
+  std::vector<std::string> pos;
+  Options o;
+  std::string crtdir, sub;
+  bool report = false;
+  try {
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a.rfind("--", 0) != 0) { if (sub.empty()) sub = a; else pos.push_back(a); continue; }
+      std::string key = a.substr(2), val; bool hasval = false;
+      size_t eq = key.find('=');
+      if (eq != std::string::npos) { val = key.substr(eq + 1); key = key.substr(0, eq); hasval = true; }
+      auto need = [&]() { if (hasval) return val; if (i + 1 >= argc) throw CompileError("option --" + key + " needs a value"); return std::string(argv[++i]); };
+      auto flag = [&]() { return hasval ? parseBool(val) : true; };
+      if (key == "quiet") o.quiet = flag();
+      else if (key == "report") report = flag();
+      else if (key == "opt") o.opt = std::stoi(need());
+      else if (key == "la") o.la = flag();
+      else if (key == "act") o.act = flag();
+      else if (key == "func" || key == "sb" || key == "ite" || key == "rmidtbls" || key == "re") flag();
+      else if (key == "metric" || key == "approxmode" || key == "wordsize") need();
+      else if (key == "copt") o.copt = std::stoi(need());
+      else if (key == "out") o.out = need();
+      else if (key == "srcout") o.srcout = need();
+      else if (key == "cc") o.cc = need();
+      else if (key == "backend") o.backend = need();
+      else if (key == "crt-dir") crtdir = need();
+      else if (key == "blob") o.blobout = need();
+      else if (key == "help") return usage();
+      else throw CompileError("unknown option --" + key);
+    }
+    if (sub != "compile" || pos.size() != 1) return usage();
+    const std::string& file = pos[0];
+    std::ifstream in(file, std::ios::binary);
+    if (!in) { std::cerr << file << ": openFile: does not exist (No such file or directory)\n"; return 1; }
+    std::stringstream ss; ss << in.rdbuf();
+    if (!o.quiet) std::cout << "Compile: " << file << " (direct mode; --la=false semantics)\n";
+    Compiled c = compileSource(ss.str(), file, o);
+    if (!o.quiet) {
+      std::cout << "SST states: ";
+      for (size_t i = 0; i < c.sst_states.size(); ++i) std::cout << (i ? ", " : "") << c.sst_states[i];
+      std::cout << "\n";
+    }
+    (void)report;
+    if (o.backend == "c") {
+      std::string txt = emitC(c.stages, c.info);
+      if (!o.srcout.empty()) { std::ofstream f(o.srcout); f << txt; }
+      if (o.out.empty()) return 0;
+      if (crtdir.empty()) { std::cerr << "--backend=c needs --crt-dir DIR (directory with crt.c)\n"; return 1; }
+      std::string cmd = o.cc + " -O" + std::to_string(o.copt) + " -xc -o '" + o.out + "' -w \"-D FLAG_WORDALIGNED\" -I'" + crtdir + "' -";
+      FILE* p = popen(cmd.c_str(), "w");
+      if (!p) { std::cerr << "cannot run " << o.cc << "\n"; return 1; }
+      fwrite(txt.data(), 1, txt.size(), p);
+      int rc = pclose(p);
+      return WIFEXITED(rc) ? WEXITSTATUS(rc) : 1;
+    }
+    if (o.backend != "hip") { std::cerr << "unknown backend " << o.backend << "\n"; return 1; }
+    std::vector<uint8_t> blob = writeBlob(c.stages, c.info);
+    if (!o.blobout.empty()) { std::ofstream f(o.blobout, std::ios::binary); f.write((const char*)blob.data(), blob.size()); }
+    if (!o.srcout.empty()) { std::ofstream f(o.srcout, std::ios::binary); f.write((const char*)blob.data(), blob.size()); }
+    if (o.out.empty()) return 0;
+    // BIN = kxrun ++ blob ++ libdir ++ trailer{blob_len u64, libdir_len u64, "KXRUNTRL"}
+    std::string dir = selfDir();
+    std::ifstream drv(dir + "/kxrun", std::ios::binary);
+    if (!drv) { std::cerr << "host driver not found: " << dir << "/kxrun (run __graft_entry__.build())\n"; return 1; }
+    std::ofstream bin(o.out, std::ios::binary | std::ios::trunc);
+    if (!bin) { std::cerr << "cannot write " << o.out << "\n"; return 1; }
+    bin << drv.rdbuf();
+    bin.write((const char*)blob.data(), blob.size());
+    bin.write(dir.data(), dir.size());
+    uint64_t bl = blob.size(), dl = dir.size();
+    bin.write((const char*)&bl, 8); bin.write((const char*)&dl, 8); bin.write("KXRUNTRL", 8);
+    bin.close();
+    chmod(o.out.c_str(), 0755);
+    return 0;
+  } catch (const CompileError& e) {
+    std::cerr << e.what() << "\n";
+    return 1;
+  } catch (const std::exception& e) {
+    std::cerr << "kexc: " << e.what() << "\n";
+    return 1;
+  }
+}

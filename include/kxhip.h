@@ -1,0 +1,122 @@
+/* kxhip.h — C ABI of the MI355X streaming-SST engine (libkxhip.so).
+ *
+ * This is the drop-in boundary for the reference's run-time hot path.  In the
+ * reference the generated code talks to its runtime through the "program
+ * interface" of crt/crt.c:101-105 (`init`, `match(phase)`) and the runtime
+ * exports readnext/consume/outputconst/outputarray/output/append/appendarray/
+ * concat/reset (crt/crt.c:107-324); the whole thing is driven by `main`/`run`
+ * (crt/crt.c:356-467).  Here the seam sits one level up: a compiled program
+ * (KXP blob, include/kxp_format.h — the table form of the IL `Pipeline`,
+ * src/KMC/Program/IL.hs:69-90) is handed to an engine that owns the state
+ * loop, the registers and the output buffer on the GPU.
+ *
+ *   reference                                   this ABI
+ *   ---------                                   --------
+ *   compileProgram … Pipeline (C.hs:529-540)    kx_load(blob)
+ *   run(phase): init_outbuf, init, match,       kx_run_device / kx_run_host /
+ *     flush_outbuf        (crt.c:356-364)         kx_run_fd
+ *   main: -t timing, phase pipeline             kx_run_fd + kx_stats (kxrun.cpp
+ *     (crt.c:372-467)                             is the `main`)
+ *   fail<K>: "Match error at input symbol %zu"  return 1, stats->fail_pos
+ *     exit(1)             (C.hs:79-81)
+ *
+ * Plain pointers and sizes only; no framework types.  Device pointers are HIP
+ * device pointers on the current device; `stream` is a hipStream_t (NULL =
+ * default stream).  One kx_program may be used by one host thread at a time.
+ *
+ * Return codes: 0 accepted; 1 match error (stats->fail_pos = number of input
+ * symbols consumed before the failing state, stats->fail_stage = pipeline
+ * stage; no output is produced — the reference itself loses the un-flushed
+ * tail, crt/crt.c:217-227); <0 runtime error, message in kx_last_error().
+ */
+#ifndef KXHIP_H
+#define KXHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kx_program kx_program;
+typedef struct kx_shard kx_shard;
+
+#define KX_OK 0
+#define KX_MATCH_ERROR 1
+#define KX_E_BLOB (-1)     /* malformed / unsupported program blob          */
+#define KX_E_HIP (-2)      /* HIP runtime error                             */
+#define KX_E_CAPACITY (-3) /* output buffer too small; *out_len = needed    */
+#define KX_E_ARG (-4)
+#define KX_E_IO (-5)
+
+enum { KX_K_SYNC = 0, KX_K_FORWARD = 1, KX_K_HEAD = 2, KX_K_BACKLEN = 3, KX_K_RESOLVE = 4, KX_K_EMIT = 5, KX_NKERNELS = 6 };
+
+typedef struct kx_stats {
+  uint64_t fail_pos;            /* valid when the call returned 1                           */
+  uint32_t fail_stage;
+  uint32_t unsynced_segments;   /* segments whose start state had to be chained sequentially */
+  uint64_t in_bytes, out_bytes;
+  float kernel_ms[KX_NKERNELS]; /* HIP-event time of each kernel group (last stage run)      */
+  float total_ms;               /* first launch → last kernel done, all stages               */
+} kx_stats;
+
+/* tuning knobs (0 = default) */
+typedef struct kx_config {
+  uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; default 4096 */
+  uint32_t block_threads;  /* workgroup size; default 256                       */
+  uint32_t collect_timing; /* record per-kernel HIP events into kx_stats        */
+} kx_config;
+
+int kx_load(const void* blob, size_t blob_len, kx_program** prog);
+void kx_free(kx_program* prog);
+const char* kx_last_error(void);
+int kx_set_config(kx_program* prog, const kx_config* cfg);
+uint32_t kx_num_stages(const kx_program* prog);
+
+/* Whole program (all pipeline stages) over one device-resident input.
+ * d_out may be NULL with cap 0 to query the exact output size (returned in
+ * *out_len with KX_E_CAPACITY).  Blocks until the result is complete. */
+int kx_run_device(kx_program* prog, const void* d_in, size_t n, void* d_out, size_t cap, size_t* out_len,
+                  kx_stats* stats, void* stream);
+
+/* Host-buffer convenience: H2D, run, D2H.  *out is malloc'd (free with kx_host_free). */
+int kx_run_host(kx_program* prog, const void* in, size_t n, void** out, size_t* out_len, kx_stats* stats);
+void kx_host_free(void* p);
+
+/* stdin → stdout contract of the produced binary (crt/crt.c:294-312,107-136): reads in_fd to EOF,
+ * writes the output to out_fd. */
+int kx_run_fd(kx_program* prog, int in_fd, int out_fd, kx_stats* stats);
+
+/* ---- sharded execution: one contiguous shard of the input per GPU -------------
+ * Per stage and per rank:
+ *   kx_shard_begin → kx_shard_forward → [exchange kx_fwd_summary] → kx_shard_fix_head
+ *   → kx_shard_backward → [exchange kx_bwd_summary, last rank first] → kx_shard_resolve
+ *   → [exchange out_len] → kx_shard_emit → kx_shard_end
+ * The only cross-shard data are the two fixed-size summaries below (the chunk-boundary
+ * hand-off); the data path needs no collective. */
+#define KX_MAX_LEAVES 256
+typedef struct kx_fwd_summary {
+  uint32_t synced;      /* 1: end_state does not depend on the incoming state                  */
+  uint32_t end_state;   /* state entering the byte after this shard (valid if synced or fixed) */
+  uint64_t head_len;    /* leading bytes that still need the incoming state (0 on first shard)  */
+  uint64_t fail_pos;    /* UINT64_MAX = no failure seen so far                                 */
+} kx_fwd_summary;
+typedef struct kx_bwd_summary {
+  uint32_t constant;                     /* 1: start leaf is the same for every end leaf */
+  uint32_t nleaves;                      /* leaves of the state at the shard end         */
+  uint8_t start_leaf[KX_MAX_LEAVES];     /* start leaf of the shard, per end leaf        */
+} kx_bwd_summary;
+
+int kx_shard_begin(kx_program* prog, uint32_t stage, const void* d_in, size_t n, int is_first, int is_last,
+                   void* stream, kx_shard** shard);
+int kx_shard_forward(kx_shard* s, kx_fwd_summary* out);
+int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out);
+int kx_shard_backward(kx_shard* s, kx_bwd_summary* out);
+int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len);
+int kx_shard_emit(kx_shard* s, void* d_out, size_t cap);
+void kx_shard_stats(kx_shard* s, kx_stats* stats);
+void kx_shard_end(kx_shard* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,997 @@
+// kx_engine.hip — MI355X (gfx950) streaming-SST execution engine behind include/kxhip.h.
+//
+// What the reference does per input symbol on one CPU core — `match<K>()`'s compare-and-branch
+// cascade plus crt.c's append/concat/output calls (Backends/C.hs:72-83,486-493; crt/crt.c:171-283)
+// — is re-designed here for a chip with 256 CUs and the whole input resident in HBM:
+//
+//   the SST's registers exist because a one-pass CPU run cannot know yet which of the live paths
+//   of the path tree will survive (Determinization.hs:24-28); with the input resident we resolve
+//   that by a second, backward sweep instead of parking bytes.  The engine therefore executes the
+//   *path form* of the program (include/kxp_format.h): forward = the SST's state sequence,
+//   backward = which leaf of each state's path tree lies on the surviving path, output = the
+//   per-step suffixes along that path, written at prefix-summed offsets.  No register bytes ever
+//   move; results are bit-identical to the register form (tests/).
+//
+// Kernels (one lane = one `segment` of the input, tables staged in LDS):
+//   k_sync     start state of every segment: run the compile-time synchronising automaton from the
+//              segment start until every possible start state has converged (speculation resolved
+//              without enumerating states at run time)
+//   k_forward  state sequence from the sync point; one state checkpoint per 64-byte piece; failure
+//              position (first symbol without transition) by atomicMin
+//   k_head     (sharded runs) the few leading bytes of a shard that need the previous shard's state
+//   k_backlen  per block: output length and start leaf for every candidate end leaf (candidates
+//              merge after about one record)
+//   k_resolve  end leaf per block from its successor's summary; block-level exclusive scan of the
+//              output lengths (k_scan_*)
+//   k_emit     per block: re-derive the piece, walk it backward along the resolved path and write
+//              the output bytes at the block's offset
+// DESIGN.md has the data layout, the byte accounting and the roofline for each.
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/kxhip.h"
+#include "../../../include/kxp_format.h"
+
+namespace {
+
+thread_local std::string g_err;
+int setErr(int code, const std::string& m) { g_err = m; return code; }
+
+#define HIPCHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return setErr(KX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+  } while (0)
+
+constexpr int PIECE = 64;                 // bytes between state checkpoints
+constexpr uint64_t UNSYNC = ~0ull;
+constexpr uint64_t NOFAIL = ~0ull;
+
+// ------------------------------------------------------------------ device-side program view
+struct DevTables {
+  const uint32_t* packed;     // [fwd | back_lo | back_hi | pool | cls] — copied verbatim into LDS
+  uint32_t packed_words;
+  uint32_t off_blo, off_bhi, off_pool, off_cls;  // word offsets inside packed
+  uint32_t nstates, nclasses, q0, maxleaves, dead;
+  const uint8_t* cls;         // global copies for the kernels that do not stage tables
+  const uint8_t* nleaves;     // [nstates+1]
+  const uint8_t* fin_leaf;    // [nstates+1]
+  const uint32_t* sync_next;
+  const uint32_t* sync_state;
+  const uint32_t* init_off;   // [maxleaves] pool offset / length of the initial closure output
+  const uint32_t* init_len;
+};
+
+struct Lds {
+  const uint32_t* fwd; const uint32_t* blo; const uint32_t* bhi; const uint8_t* pool; const uint8_t* cls;
+};
+
+__device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) {
+  for (uint32_t i = threadIdx.x; i < T.packed_words; i += blockDim.x) smem[i] = T.packed[i];
+  __syncthreads();
+  Lds L;
+  L.fwd = smem; L.blo = smem + T.off_blo; L.bhi = smem + T.off_bhi;
+  L.pool = (const uint8_t*)(smem + T.off_pool); L.cls = (const uint8_t*)(smem + T.off_cls);
+  return L;
+}
+
+struct Flags {               // one per shard, device memory
+  unsigned long long fail_pos;
+  uint32_t end_state;
+  uint32_t unsynced;
+  unsigned long long total_len;
+  uint32_t first_merged;     // lowest block index whose start leaf is independent of its end leaf
+  uint32_t pad;
+};
+
+// ------------------------------------------------------------------------------- k_sync
+// Segment k starts at byte k*seg with an unknown state.  sync_next/sync_state is the subset
+// automaton "set of all states → …" built by the compiler; once it reaches a singleton the state
+// is known no matter what preceded.  Segments that do not converge inside their own bytes are
+// marked UNSYNC and are simply run through by the preceding lane.
+__global__ void k_sync(const uint8_t* __restrict__ in, uint64_t n, uint64_t seg, uint32_t nseg, int first_known,
+                       uint64_t* __restrict__ seg_pos, uint16_t* __restrict__ seg_state, Flags* flags, DevTables T) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nseg) return;
+  if (k == 0 && first_known) { seg_pos[0] = 0; seg_state[0] = (uint16_t)T.q0; return; }
+  uint64_t pos = (uint64_t)k * seg;
+  uint64_t limit = pos + seg < n ? pos + seg : n;
+  uint32_t sid = 0;
+  uint32_t st = T.sync_state[0];
+  while (st == KXP_SYNC_MULTI && pos < limit) {
+    sid = T.sync_next[sid * T.nclasses + T.cls[in[pos]]];
+    ++pos;
+    if (sid == KXP_SYNC_UNKNOWN) { st = KXP_SYNC_UNKNOWN; break; }
+    st = T.sync_state[sid];
+  }
+  if (st < 0xFFFFu) { seg_pos[k] = pos; seg_state[k] = (uint16_t)st; }
+  else { seg_pos[k] = UNSYNC; seg_state[k] = 0; atomicAdd(&flags->unsynced, 1u); }
+}
+
+// ---------------------------------------------------------------------------- k_forward
+// fwd[q*C + c] = next | back_row_offset<<16 ; state `dead` absorbs missing transitions so the
+// hot loop carries no failure branch; the exact position is recovered per 16-byte chunk.
+__device__ __forceinline__ uint32_t byte_of(const uint4& v, int j) {
+  uint32_t w = j < 4 ? v.x : j < 8 ? v.y : j < 12 ? v.z : v.w;
+  return (w >> ((j & 3) * 8)) & 0xFFu;
+}
+
+__global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t nseg,
+                          const uint64_t* __restrict__ seg_pos, const uint16_t* __restrict__ seg_state,
+                          uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nseg) return;
+  uint64_t pos = seg_pos[k];
+  if (pos == UNSYNC) return;
+  uint32_t j = k + 1;
+  while (j < nseg && seg_pos[j] == UNSYNC) ++j;
+  const bool last = j >= nseg;
+  const uint64_t end = last ? n : seg_pos[j];
+  const uint32_t C = T.nclasses, dead = T.dead;
+  uint32_t q = seg_state[k];
+  bool failed = false;
+  while (pos < end && (pos & 15)) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
+    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
+    if (nq == dead) { failed = true; break; }
+    q = nq; ++pos;
+  }
+  while (!failed && pos + 16 <= end) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
+    const uint4 v = *reinterpret_cast<const uint4*>(in + pos);
+    uint32_t q0 = q;
+#pragma unroll
+    for (int b = 0; b < 16; ++b) q = L.fwd[q * C + L.cls[byte_of(v, b)]] & 0xFFFFu;
+    if (q == dead) {  // locate the first missing transition inside this chunk
+      q = q0;
+      for (int b = 0; b < 16; ++b) {
+        uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
+        if (nq == dead) break;
+        q = nq; ++pos;
+      }
+      failed = true;
+      break;
+    }
+    pos += 16;
+  }
+  while (!failed && pos < end) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
+    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
+    if (nq == dead) { failed = true; break; }
+    q = nq; ++pos;
+  }
+  if (failed) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
+  if (last) {
+    flags->end_state = q;
+    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)q;
+  }
+}
+
+// sequential run over the head of a shard (bytes before the first synchronised segment)
+__global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head_len, uint32_t q,
+                       uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  if (blockIdx.x || threadIdx.x) return;
+  const uint32_t C = T.nclasses, dead = T.dead;
+  for (uint64_t pos = 0; pos < head_len; ++pos) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
+    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
+    if (nq == dead) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
+    q = nq;
+  }
+  if (head_len == n) {
+    flags->end_state = q;
+    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)q;
+  }
+}
+
+// --------------------------------------------------------------- piece helpers (backward sweeps)
+// A piece is 64 input bytes held in 16 VGPRs; forward re-derivation from its checkpoint yields the
+// back-row offset of every step (kept in registers; all loops are fully unrolled so that the
+// arrays are statically indexed and never spill to scratch).
+__device__ __forceinline__ void load_piece(const uint8_t* __restrict__ in, uint64_t n, uint64_t pstart, uint32_t (&w)[16]) {
+  if (pstart + PIECE <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(in + pstart);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { uint4 v = p[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { uint64_t a = pstart + 4 * i + b; if (a < n) x |= (uint32_t)in[a] << (8 * b); }
+      w[i] = x;
+    }
+  }
+}
+
+__device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t q, uint32_t C, const Lds& L, uint32_t (&bo)[PIECE]) {
+#pragma unroll
+  for (int t = 0; t < PIECE; ++t) {
+    uint32_t byte = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
+    uint32_t e = L.fwd[q * C + L.cls[byte]];
+    bo[t] = e >> 16;
+    q = e & 0xFFFFu;
+  }
+}
+
+// ---------------------------------------------------------------------------- k_backlen
+// back_lo[row + leaf] = parent | copy<<8 | (bytes appended on this step)<<9.
+// For block m and every leaf the block could end in: where the path enters the block (start leaf)
+// and how many output bytes the block contributes.  Candidates are advanced piece by piece and
+// collapse to one as soon as they agree.
+template <int MAXC>
+__global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
+                          const uint16_t* __restrict__ chk, const Flags* flags, int is_last,
+                          uint8_t* __restrict__ bs_start, uint32_t* __restrict__ bs_len, uint8_t* __restrict__ bs_merged,
+                          uint8_t* __restrict__ bs_mstart, uint32_t Lc, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nblk) return;
+  const uint64_t bstart = (uint64_t)m * blk;
+  const uint64_t bend = bstart + blk < n ? bstart + blk : n;
+  const uint32_t C = T.nclasses;
+  const uint32_t qe = bend == n ? flags->end_state : chk[bend >> 6];
+  uint8_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];
+  uint32_t nc, nact;
+  uint32_t known = 0xFFFFFFFFu;
+  if (bend == n && is_last) { nc = 1; known = T.fin_leaf[qe]; cl[0] = (uint8_t)known; }
+  else { nc = T.nleaves[qe]; if (nc > MAXC) nc = MAXC; for (uint32_t j = 0; j < nc; ++j) cl[j] = (uint8_t)j; }
+  for (uint32_t j = 0; j < nc; ++j) { clen[j] = 0; pre[j] = 0; }
+  nact = nc;
+  const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
+  for (uint32_t p = npieces; p-- > 0;) {
+    const uint64_t pstart = bstart + (uint64_t)p * PIECE;
+    const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
+    uint32_t w[16], bo[PIECE];
+    load_piece(in, n, pstart, w);
+    piece_forward(w, chk[pstart >> 6], C, L, bo);
+    for (uint32_t j = 0; j < nact; ++j) {
+      uint32_t leaf = cl[j], sum = 0;
+#pragma unroll
+      for (int t = PIECE - 1; t >= 0; --t) {
+        if (t < plen) { uint32_t lo = L.blo[bo[t] + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; }
+      }
+      cl[j] = (uint8_t)leaf; clen[j] += sum;
+    }
+    if (nact > 1) {
+      bool same = true;
+      for (uint32_t j = 1; j < nact; ++j) same = same && cl[j] == cl[0];
+      if (same) { for (uint32_t j = 0; j < nc; ++j) pre[j] = clen[j]; nact = 1; }
+    }
+  }
+  const bool merged = nact == 1;
+  if (known != 0xFFFFFFFFu) {
+    bs_start[(size_t)m * Lc + known] = cl[0]; bs_len[(size_t)m * Lc + known] = clen[0];
+  } else if (merged) {  // after merging only candidate 0 kept accumulating
+    const uint32_t tail = clen[0] - pre[0];
+    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[0]; bs_len[(size_t)m * Lc + j] = pre[j] + tail; }
+  } else {
+    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[j]; bs_len[(size_t)m * Lc + j] = clen[j]; }
+  }
+  bs_merged[m] = merged ? 1 : 0;
+  bs_mstart[m] = cl[0];
+}
+
+// ---------------------------------------------------------------------------- k_resolve
+// End leaf of block m = start leaf of block m+1 under *its* end leaf; blocks whose candidates merged
+// cut the dependency chain, so this is a short local walk (usually one step).
+__global__ void k_resolve(uint32_t nblk, uint32_t end_leaf, const uint8_t* __restrict__ bs_start,
+                          const uint32_t* __restrict__ bs_len, const uint8_t* __restrict__ bs_merged,
+                          const uint8_t* __restrict__ bs_mstart, uint32_t Lc, uint8_t* __restrict__ E,
+                          uint32_t* __restrict__ len, unsigned long long* __restrict__ wsum) {
+  __shared__ unsigned long long red[256];
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t mylen = 0;
+  if (m < nblk) {
+    uint32_t e;
+    if (m == nblk - 1) e = end_leaf;
+    else {
+      uint32_t j = m + 1;
+      while (!bs_merged[j] && j < nblk - 1) ++j;
+      uint32_t leaf = bs_merged[j] ? bs_mstart[j] : bs_start[(size_t)j * Lc + end_leaf];
+      for (uint32_t i = j - 1; i > m; --i) leaf = bs_start[(size_t)i * Lc + leaf];
+      e = leaf;
+    }
+    E[m] = (uint8_t)e;
+    mylen = bs_len[(size_t)m * Lc + e];
+    len[m] = mylen;
+  }
+  red[threadIdx.x] = mylen;
+  __syncthreads();
+  for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) wsum[blockIdx.x] = red[0];
+}
+
+// exclusive scan of the per-workgroup sums (one workgroup), then of the blocks inside each group
+__global__ void k_scan_groups(uint32_t ngroups, const unsigned long long* __restrict__ wsum,
+                              unsigned long long* __restrict__ woff, Flags* flags) {
+  __shared__ unsigned long long buf[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < ngroups; base += blockDim.x) {
+    uint32_t i = base + threadIdx.x;
+    unsigned long long v = i < ngroups ? wsum[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+      unsigned long long x = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += x;
+      __syncthreads();
+    }
+    if (i < ngroups) woff[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == blockDim.x - 1) carry += buf[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) flags->total_len = carry;
+}
+
+__global__ void k_scan_blocks(uint32_t nblk, const uint32_t* __restrict__ len, const unsigned long long* __restrict__ woff,
+                              unsigned long long* __restrict__ off) {
+  __shared__ unsigned long long buf[256];
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = m < nblk ? len[m] : 0;
+  buf[threadIdx.x] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+    unsigned long long x = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+    __syncthreads();
+    buf[threadIdx.x] += x;
+    __syncthreads();
+  }
+  if (m < nblk) off[m] = woff[blockIdx.x] + buf[threadIdx.x] - v;
+}
+
+// start leaf of the whole shard per end leaf (for the neighbouring rank); one thread
+__global__ void k_shard_map(uint32_t nblk, uint32_t nleaves_end, const uint8_t* __restrict__ bs_start,
+                            const uint8_t* __restrict__ bs_merged, const uint8_t* __restrict__ bs_mstart, uint32_t Lc,
+                            uint8_t* __restrict__ map_out, uint32_t* __restrict__ constant_out) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t first = nblk;
+  for (uint32_t m = 0; m < nblk; ++m) if (bs_merged[m]) { first = m; break; }
+  if (first < nblk) {
+    uint32_t leaf = bs_mstart[first];
+    for (uint32_t i = first; i-- > 0;) leaf = bs_start[(size_t)i * Lc + leaf];
+    for (uint32_t e = 0; e < nleaves_end; ++e) map_out[e] = (uint8_t)leaf;
+    *constant_out = 1;
+  } else {
+    for (uint32_t e = 0; e < nleaves_end; ++e) {
+      uint32_t leaf = e;
+      for (uint32_t i = nblk; i-- > 0;) leaf = bs_start[(size_t)i * Lc + leaf];
+      map_out[e] = (uint8_t)leaf;
+    }
+    *constant_out = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------- k_emit
+// back_hi[row + leaf] = pool offset of the constant appended on that step.  Output is produced
+// back to front inside the block, starting from the block's end offset.
+__global__ void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
+                       const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
+                       const uint32_t* __restrict__ len, const unsigned long long* __restrict__ off,
+                       const uint8_t* __restrict__ bs_start, uint32_t Lc, int is_first,
+                       uint8_t* __restrict__ out, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= nblk) return;
+  const uint64_t bstart = (uint64_t)m * blk;
+  const uint64_t bend = bstart + blk < n ? bstart + blk : n;
+  const uint32_t C = T.nclasses;
+  // the initial closure's output precedes everything on the first shard
+  uint32_t init_shift = 0;
+  if (is_first) init_shift = T.init_len[bs_start[(size_t)0 * Lc + E[0]]];
+  uint64_t o = init_shift + off[m] + len[m];
+  uint32_t leaf = E[m];
+  const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
+  for (uint32_t p = npieces; p-- > 0;) {
+    const uint64_t pstart = bstart + (uint64_t)p * PIECE;
+    const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
+    uint32_t w[16], bo[PIECE];
+    load_piece(in, n, pstart, w);
+    piece_forward(w, chk[pstart >> 6], C, L, bo);
+#pragma unroll
+    for (int t = PIECE - 1; t >= 0; --t) {
+      if (t < plen) {
+        const uint32_t lo = L.blo[bo[t] + leaf];
+        const uint32_t hi = L.bhi[bo[t] + leaf];
+        const uint32_t copy = (lo >> 8) & 1u;
+        uint32_t cl = (lo >> 9) - copy;
+        while (cl > 0) { --cl; out[--o] = L.pool[hi + cl]; }
+        if (copy) out[--o] = (uint8_t)((w[t >> 2] >> ((t & 3) * 8)) & 0xFFu);
+        leaf = lo & 0xFFu;
+      }
+    }
+  }
+  if (m == 0 && is_first) {
+    const uint32_t io = T.init_off[leaf], il = T.init_len[leaf];
+    for (uint32_t i = 0; i < il; ++i) out[i] = L.pool[io + i];
+  }
+}
+
+// =============================================================================== host side
+struct Stage {
+  uint32_t nstates = 0, nclasses = 0, q0 = 0, maxleaves = 1;
+  std::vector<uint8_t> h_nleaves, h_fin_leaf;          // host copies for the control path
+  std::vector<uint32_t> h_init_off, h_init_len;
+  std::vector<uint8_t> h_pool;
+  void* d_all = nullptr;                               // one allocation holding every table
+  DevTables T{};
+  size_t lds_bytes = 0;
+};
+
+struct Arena {  // grow-only device workspace, reused across runs
+  char* base = nullptr; size_t cap = 0, used = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (base) (void)hipFree(base);
+    base = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + (1 << 20);
+    HIPCHECK(hipMalloc((void**)&base, want));
+    cap = want;
+    return 0;
+  }
+  void reset() { used = 0; }
+  template <typename Ty> Ty* take(size_t count) {
+    used = (used + 255) & ~(size_t)255;
+    Ty* p = reinterpret_cast<Ty*>(base + used);
+    used += count * sizeof(Ty);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct kx_program {
+  std::vector<Stage> stages;
+  kx_config cfg{4096, 256, 0};
+  Arena arena;                     // shard workspace
+  void* stagebuf[2] = {nullptr, nullptr};   // ping-pong buffers between pipeline stages
+  size_t stagecap[2] = {0, 0};
+  hipEvent_t ev[KX_NKERNELS + 1] = {};
+  bool have_events = false;
+  kx_shard* live = nullptr;
+};
+
+struct kx_shard {
+  kx_program* prog; Stage* st; uint32_t stage;
+  const uint8_t* in; uint64_t n; int is_first, is_last; hipStream_t stream;
+  uint64_t seg; uint32_t nseg, nblk, Lc, ngroups;
+  // workspace
+  uint64_t* seg_pos; uint16_t* seg_state; uint16_t* chk; Flags* flags;
+  uint8_t *bs_start, *bs_merged, *bs_mstart, *E, *d_map; uint32_t *bs_len, *len, *d_const;
+  unsigned long long *off, *wsum, *woff;
+  // control state mirrored on the host
+  Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0;
+  kx_stats stats{};
+};
+
+namespace {
+
+size_t pad4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
+  if (c + 64 > end) return setErr(KX_E_BLOB, "truncated stage header");
+  uint32_t h[16];
+  memcpy(h, c, 64); c += 64;
+  if (h[0] != KXP_STAGE_MAGIC) return setErr(KX_E_BLOB, "bad stage magic");
+  const uint32_t nstates = h[1], C = h[2], q0 = h[3], nactions = h[5], nops = h[6], nconsts = h[7], cpl = h[8];
+  const uint32_t Lm = h[9], nback = h[10], npc = h[11], pcpl = h[12], nsync = h[13];
+  const size_t sc = (size_t)nstates * C;
+  const uint8_t* cls = c; c += 256;
+  const uint16_t* delta = (const uint16_t*)c; c += pad4(sc * 2);
+  c += sc * 4;                                   // act        (register form: not used by the engine)
+  c += (size_t)nstates * 4;                      // final_act
+  c += ((size_t)nactions + 1) * 4;               // act_off
+  c += (size_t)nops * 8;                         // ops
+  c += ((size_t)nconsts + 1) * 4; c += pad4(cpl);  // consts
+  const uint32_t* pback = (const uint32_t*)c; c += sc * 4;
+  const uint8_t* nleaves = c; c += pad4(nstates);
+  const uint8_t* fin_leaf = c; c += pad4(nstates);
+  const uint32_t* back = (const uint32_t*)c; c += (size_t)nback * Lm * 4;
+  const uint32_t* pcoff = (const uint32_t*)c; c += ((size_t)npc + 1) * 4;
+  const uint8_t* pcpool = c; c += pad4(pcpl);
+  const uint32_t* init_const = (const uint32_t*)c; c += (size_t)Lm * 4;
+  const uint32_t* sync_next = (const uint32_t*)c; c += (size_t)nsync * C * 4;
+  const uint32_t* sync_state = (const uint32_t*)c; c += (size_t)nsync * 4;
+  if (c > end) return setErr(KX_E_BLOB, "truncated stage body");
+  if (nstates == 0 || nstates >= 0xFFFE || C == 0 || Lm == 0 || Lm > 254)
+    return setErr(KX_E_BLOB, "program outside engine limits (states/leaves)");
+
+  S.nstates = nstates; S.nclasses = C; S.q0 = q0; S.maxleaves = Lm;
+  // ragged back rows: row b keeps entries up to its last live leaf
+  std::vector<uint32_t> rowoff(nback), blo, bhi;
+  for (uint32_t b = 0; b < nback; ++b) {
+    uint32_t rl = 1;
+    for (uint32_t j = 0; j < Lm; ++j) if (back[(size_t)b * Lm + j] != KXP_DEAD_LEAF) rl = j + 1;
+    rowoff[b] = (uint32_t)blo.size();
+    for (uint32_t j = 0; j < rl; ++j) {
+      uint32_t e = back[(size_t)b * Lm + j];
+      if (e == KXP_DEAD_LEAF) { blo.push_back(0); bhi.push_back(0); continue; }
+      uint32_t parent = e & 0xFF, copy = (e >> 8) & 1, pc = e >> 9;
+      uint32_t clen = pcoff[pc + 1] - pcoff[pc];
+      if (clen + copy >= (1u << 23)) return setErr(KX_E_BLOB, "path constant too long");
+      blo.push_back(parent | (copy << 8) | ((clen + copy) << 9));
+      bhi.push_back(pcoff[pc]);
+    }
+  }
+  // a lane may probe row+leaf for a leaf beyond the row's live range only on a dead path; pad so
+  // that even then it stays inside the table
+  for (uint32_t j = 0; j < Lm; ++j) { blo.push_back(0); bhi.push_back(0); }
+  if (blo.size() >= 65536) return setErr(KX_E_BLOB, "backward table exceeds 65535 entries");
+  const uint32_t dead = nstates;
+  std::vector<uint32_t> fwd((size_t)(nstates + 1) * C);
+  for (uint32_t q = 0; q < nstates; ++q)
+    for (uint32_t k = 0; k < C; ++k) {
+      uint16_t d = delta[(size_t)q * C + k];
+      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? dead : (d | (rowoff[pback[(size_t)q * C + k]] << 16));
+    }
+  for (uint32_t k = 0; k < C; ++k) fwd[(size_t)dead * C + k] = dead;
+
+  // packed LDS image: fwd | back_lo | back_hi | pool | cls
+  std::vector<uint32_t> packed(fwd);
+  const uint32_t off_blo = (uint32_t)packed.size();
+  packed.insert(packed.end(), blo.begin(), blo.end());
+  const uint32_t off_bhi = (uint32_t)packed.size();
+  packed.insert(packed.end(), bhi.begin(), bhi.end());
+  const uint32_t off_pool = (uint32_t)packed.size();
+  packed.resize(packed.size() + pad4(pcpl + 4) / 4, 0);
+  memcpy(&packed[off_pool], pcpool, pcpl);
+  const uint32_t off_cls = (uint32_t)packed.size();
+  packed.resize(packed.size() + 64);
+  memcpy(&packed[off_cls], cls, 256);
+  S.lds_bytes = packed.size() * 4;
+  if (S.lds_bytes > 150 * 1024) return setErr(KX_E_BLOB, "program tables exceed the LDS budget (150 KiB)");
+
+  S.h_nleaves.assign(nleaves, nleaves + nstates); S.h_nleaves.push_back(1);
+  S.h_fin_leaf.assign(fin_leaf, fin_leaf + nstates); S.h_fin_leaf.push_back(KXP_NO_LEAF);
+  S.h_pool.assign(pcpool, pcpool + pcpl);
+  S.h_init_off.resize(Lm); S.h_init_len.resize(Lm);
+  for (uint32_t j = 0; j < Lm; ++j) { S.h_init_off[j] = pcoff[init_const[j]]; S.h_init_len[j] = pcoff[init_const[j] + 1] - pcoff[init_const[j]]; }
+
+  // one device allocation: packed | cls | nleaves | fin_leaf | sync_next | sync_state | init_off | init_len
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t o_packed = 0, o_cls = o_packed + al(packed.size() * 4), o_nl = o_cls + 256, o_fl = o_nl + al(nstates + 1),
+         o_sn = o_fl + al(nstates + 1), o_ss = o_sn + al((size_t)nsync * C * 4), o_io = o_ss + al((size_t)nsync * 4),
+         o_il = o_io + al(Lm * 4), total = o_il + al(Lm * 4);
+  std::vector<uint8_t> img(total, 0);
+  memcpy(&img[o_packed], packed.data(), packed.size() * 4);
+  memcpy(&img[o_cls], cls, 256);
+  memcpy(&img[o_nl], S.h_nleaves.data(), nstates + 1);
+  memcpy(&img[o_fl], S.h_fin_leaf.data(), nstates + 1);
+  memcpy(&img[o_sn], sync_next, (size_t)nsync * C * 4);
+  memcpy(&img[o_ss], sync_state, (size_t)nsync * 4);
+  memcpy(&img[o_io], S.h_init_off.data(), Lm * 4);
+  memcpy(&img[o_il], S.h_init_len.data(), Lm * 4);
+  HIPCHECK(hipMalloc(&S.d_all, total));
+  HIPCHECK(hipMemcpy(S.d_all, img.data(), total, hipMemcpyHostToDevice));
+  char* d = (char*)S.d_all;
+  DevTables& T = S.T;
+  T.packed = (const uint32_t*)(d + o_packed); T.packed_words = (uint32_t)packed.size();
+  T.off_blo = off_blo; T.off_bhi = off_bhi; T.off_pool = off_pool; T.off_cls = off_cls;
+  T.nstates = nstates; T.nclasses = C; T.q0 = q0; T.maxleaves = Lm; T.dead = dead;
+  T.cls = (const uint8_t*)(d + o_cls); T.nleaves = (const uint8_t*)(d + o_nl); T.fin_leaf = (const uint8_t*)(d + o_fl);
+  T.sync_next = (const uint32_t*)(d + o_sn); T.sync_state = (const uint32_t*)(d + o_ss);
+  T.init_off = (const uint32_t*)(d + o_io); T.init_len = (const uint32_t*)(d + o_il);
+  return 0;
+}
+
+int setLds(const void* fn, size_t bytes) {
+  HIPCHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+float evMs(hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+
+}  // namespace
+
+// ================================================================================= C ABI
+extern "C" {
+
+const char* kx_last_error(void) { return g_err.c_str(); }
+
+int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
+  if (!blob || !prog) return setErr(KX_E_ARG, "null argument");
+  const uint8_t* b = (const uint8_t*)blob;
+  if (blob_len < 20 || memcmp(b, KXP_MAGIC, 8)) return setErr(KX_E_BLOB, "not a KXP blob");
+  uint32_t ver, ns, il;
+  memcpy(&ver, b + 8, 4); memcpy(&ns, b + 12, 4); memcpy(&il, b + 16, 4);
+  if (ver != KXP_VERSION || ns == 0) return setErr(KX_E_BLOB, "unsupported KXP version");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return setErr(KX_E_HIP, "no HIP device available: the engine has no CPU fallback");
+  const uint8_t* c = b + 20 + pad4(il);
+  auto* p = new kx_program;
+  p->stages.resize(ns);
+  for (uint32_t s = 0; s < ns; ++s) {
+    int rc = parseStage(c, b + blob_len, p->stages[s]);
+    if (rc) { kx_free(p); return rc; }
+  }
+  size_t lds = 0;
+  for (auto& s : p->stages) lds = s.lds_bytes > lds ? s.lds_bytes : lds;
+  int rc = setLds((const void*)k_forward, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_head, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<32>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<256>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_emit, lds); if (rc) { kx_free(p); return rc; }
+  *prog = p;
+  return 0;
+}
+
+void kx_free(kx_program* p) {
+  if (!p) return;
+  for (auto& s : p->stages) if (s.d_all) (void)hipFree(s.d_all);
+  if (p->arena.base) (void)hipFree(p->arena.base);
+  for (int i = 0; i < 2; ++i) if (p->stagebuf[i]) (void)hipFree(p->stagebuf[i]);
+  if (p->have_events) for (auto& e : p->ev) (void)hipEventDestroy(e);
+  delete p;
+}
+
+int kx_set_config(kx_program* p, const kx_config* cfg) {
+  if (!p || !cfg) return setErr(KX_E_ARG, "null argument");
+  kx_config c = *cfg;
+  if (c.segment_bytes == 0) c.segment_bytes = 4096;
+  if (c.block_threads == 0) c.block_threads = 256;
+  if (c.segment_bytes % PIECE || c.block_threads % 64 || c.block_threads > 1024)
+    return setErr(KX_E_ARG, "segment_bytes must be a multiple of 64, block_threads a multiple of 64 ≤ 1024");
+  p->cfg = c;
+  return 0;
+}
+
+uint32_t kx_num_stages(const kx_program* p) { return p ? (uint32_t)p->stages.size() : 0; }
+
+int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, int is_first, int is_last,
+                   void* stream, kx_shard** out) {
+  if (!p || !out || stage >= p->stages.size()) return setErr(KX_E_ARG, "bad program/stage");
+  if (n && (!d_in || ((uintptr_t)d_in & 15))) return setErr(KX_E_ARG, "input must be 16-byte aligned");
+  if (p->live) return setErr(KX_E_ARG, "a shard is already open on this program");
+  auto* s = new kx_shard;
+  s->prog = p; s->st = &p->stages[stage]; s->stage = stage;
+  s->in = (const uint8_t*)d_in; s->n = n; s->is_first = is_first; s->is_last = is_last; s->stream = (hipStream_t)stream;
+  s->seg = p->cfg.segment_bytes;
+  uint64_t ns = n ? (n + s->seg - 1) / s->seg : 1;
+  if (ns > 0x7FFFFFF0ull) { delete s; return setErr(KX_E_ARG, "input too large for the configured segment size"); }
+  s->nseg = (uint32_t)ns; s->nblk = s->nseg; s->Lc = s->st->maxleaves;
+  const uint32_t bt = p->cfg.block_threads;
+  s->ngroups = (s->nblk + bt - 1) / bt;
+  // workspace layout
+  Arena& A = p->arena;
+  size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / PIECE + 4) * 2 + sizeof(Flags) +
+                (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
+                256 * 24;
+  int rc = A.reserve(need);
+  if (rc) { delete s; return rc; }
+  A.reset();
+  s->seg_pos = A.take<uint64_t>(s->nseg); s->seg_state = A.take<uint16_t>(s->nseg);
+  s->chk = A.take<uint16_t>(n / PIECE + 4); s->flags = A.take<Flags>(1);
+  s->bs_start = A.take<uint8_t>((size_t)s->nblk * s->Lc); s->bs_len = A.take<uint32_t>((size_t)s->nblk * s->Lc);
+  s->bs_merged = A.take<uint8_t>(s->nblk); s->bs_mstart = A.take<uint8_t>(s->nblk); s->E = A.take<uint8_t>(s->nblk);
+  s->len = A.take<uint32_t>(s->nblk); s->off = A.take<unsigned long long>(s->nblk);
+  s->wsum = A.take<unsigned long long>(s->ngroups); s->woff = A.take<unsigned long long>(s->ngroups);
+  s->d_map = A.take<uint8_t>(KX_MAX_LEAVES); s->d_const = A.take<uint32_t>(4);
+  if (!p->have_events) {
+    for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete s; return setErr(KX_E_HIP, "hipEventCreate failed"); }
+    p->have_events = true;
+  }
+  s->stats.in_bytes = n;
+  p->live = s;
+  *out = s;
+  return 0;
+}
+
+static int readFlags(kx_shard* s) {
+  HIPCHECK(hipMemcpyAsync(&s->hflags, s->flags, sizeof(Flags), hipMemcpyDeviceToHost, s->stream));
+  HIPCHECK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+static void fillFwd(kx_shard* s, kx_fwd_summary* out) {
+  out->synced = s->have_end ? 1 : 0;
+  out->end_state = s->have_end ? s->hflags.end_state : 0;
+  out->head_len = s->head_len;
+  out->fail_pos = s->hflags.fail_pos;
+}
+
+int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
+  if (!s || !out) return setErr(KX_E_ARG, "null argument");
+  kx_program* p = s->prog; Stage& S = *s->st;
+  const uint32_t bt = p->cfg.block_threads;
+  const bool timing = p->cfg.collect_timing;
+  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0; init.first_merged = 0xFFFFFFFFu;
+  HIPCHECK(hipMemcpyAsync(s->flags, &init, sizeof(Flags), hipMemcpyHostToDevice, s->stream));
+  if (s->n == 0) {  // nothing to scan: the state entering byte 0 is also the end state
+    s->hflags = init; s->head_len = 0; s->have_end = s->is_first != 0;
+    fillFwd(s, out);
+    return 0;
+  }
+  const uint32_t grid = (s->nseg + bt - 1) / bt;
+  if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
+  hipLaunchKernelGGL(k_sync, dim3(grid), dim3(bt), 0, s->stream, s->in, s->n, s->seg, s->nseg, s->is_first,
+                     s->seg_pos, s->seg_state, s->flags, S.T);
+  if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
+  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->nseg, s->seg_pos,
+                     s->seg_state, s->chk, s->flags, S.T);
+  if (timing) HIPCHECK(hipEventRecord(p->ev[2], s->stream));
+  HIPCHECK(hipGetLastError());
+  int rc = readFlags(s);
+  if (rc) return rc;
+  if (timing) { s->stats.kernel_ms[KX_K_SYNC] = evMs(p->ev[0], p->ev[1]); s->stats.kernel_ms[KX_K_FORWARD] = evMs(p->ev[1], p->ev[2]); }
+  s->stats.unsynced_segments = s->hflags.unsynced;
+  // head = bytes before the first synchronised segment (0 on a first shard)
+  if (s->is_first) { s->head_len = 0; s->have_end = true; }
+  else {
+    // find the first synced segment: unsynced ones are rare, probe from the front
+    uint64_t hp = UNSYNC;
+    for (uint32_t k = 0; k < s->nseg; ++k) {
+      HIPCHECK(hipMemcpy(&hp, s->seg_pos + k, 8, hipMemcpyDeviceToHost));
+      if (hp != UNSYNC) break;
+    }
+    s->head_len = hp == UNSYNC ? s->n : hp;
+    s->have_end = hp != UNSYNC;
+  }
+  fillFwd(s, out);
+  return 0;
+}
+
+int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out) {
+  if (!s || !out) return setErr(KX_E_ARG, "null argument");
+  kx_program* p = s->prog; Stage& S = *s->st;
+  if (!s->is_first && s->head_len > 0) {
+    if (incoming_state > S.nstates) return setErr(KX_E_ARG, "incoming state out of range");
+    const bool timing = p->cfg.collect_timing;
+    if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len, incoming_state,
+                       s->chk, s->flags, S.T);
+    if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
+    HIPCHECK(hipGetLastError());
+    int rc = readFlags(s);
+    if (rc) return rc;
+    if (timing) s->stats.kernel_ms[KX_K_HEAD] = evMs(p->ev[0], p->ev[1]);
+  } else if (!s->is_first && s->n == 0) {
+    s->hflags.end_state = incoming_state;
+  }
+  s->have_end = true;
+  if (s->is_last && s->hflags.fail_pos == NOFAIL && S.h_fin_leaf[s->hflags.end_state] == KXP_NO_LEAF)
+    s->hflags.fail_pos = s->n;  // end of input in a non-final state (C.hs NextI fallback → FailI)
+  fillFwd(s, out);
+  return 0;
+}
+
+int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
+  if (!s || !out) return setErr(KX_E_ARG, "null argument");
+  kx_program* p = s->prog; Stage& S = *s->st;
+  memset(out, 0, sizeof *out);
+  const uint32_t nle = S.h_nleaves[s->hflags.end_state];
+  out->nleaves = nle;
+  if (s->n == 0) {  // identity map
+    out->constant = 0;
+    for (uint32_t e = 0; e < nle; ++e) out->start_leaf[e] = (uint8_t)e;
+    return 0;
+  }
+  const uint32_t bt = p->cfg.block_threads;
+  const uint32_t grid = (s->nblk + bt - 1) / bt;
+  const bool timing = p->cfg.collect_timing;
+  if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
+  if (s->Lc <= 32)
+    hipLaunchKernelGGL((k_backlen<32>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
+                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, S.T);
+  else
+    hipLaunchKernelGGL((k_backlen<256>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
+                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, S.T);
+  if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
+  HIPCHECK(hipGetLastError());
+  if (!s->is_first) {  // the neighbouring rank needs our start leaf as a function of our end leaf
+    hipLaunchKernelGGL(k_shard_map, dim3(1), dim3(64), 0, s->stream, s->nblk, nle, s->bs_start, s->bs_merged,
+                       s->bs_mstart, s->Lc, s->d_map, s->d_const);
+    HIPCHECK(hipMemcpyAsync(out->start_leaf, s->d_map, nle, hipMemcpyDeviceToHost, s->stream));
+    HIPCHECK(hipMemcpyAsync(&out->constant, s->d_const, 4, hipMemcpyDeviceToHost, s->stream));
+  }
+  HIPCHECK(hipStreamSynchronize(s->stream));
+  if (timing) s->stats.kernel_ms[KX_K_BACKLEN] = evMs(p->ev[0], p->ev[1]);
+  return 0;
+}
+
+int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
+  if (!s || !out_len) return setErr(KX_E_ARG, "null argument");
+  kx_program* p = s->prog; Stage& S = *s->st;
+  if (s->is_last) end_leaf = S.h_fin_leaf[s->hflags.end_state];
+  if (end_leaf >= S.h_nleaves[s->hflags.end_state]) return setErr(KX_E_ARG, "end leaf out of range");
+  if (s->n == 0) {
+    s->init_shift = s->is_first ? S.h_init_len[end_leaf] : 0;
+    s->out_len = s->init_shift;
+    *out_len = s->out_len;
+    s->hflags.first_merged = end_leaf;  // remembered as the start leaf
+    return 0;
+  }
+  const uint32_t bt = p->cfg.block_threads;
+  const bool timing = p->cfg.collect_timing;
+  if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
+  hipLaunchKernelGGL(k_resolve, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, end_leaf, s->bs_start, s->bs_len,
+                     s->bs_merged, s->bs_mstart, s->Lc, s->E, s->len, s->wsum);
+  hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s->stream, s->ngroups, s->wsum, s->woff, s->flags);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, s->len, s->woff, s->off);
+  if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
+  HIPCHECK(hipGetLastError());
+  uint8_t e0 = 0;
+  HIPCHECK(hipMemcpyAsync(&e0, s->E, 1, hipMemcpyDeviceToHost, s->stream));
+  int rc = readFlags(s);
+  if (rc) return rc;
+  if (timing) s->stats.kernel_ms[KX_K_RESOLVE] = evMs(p->ev[0], p->ev[1]);
+  s->init_shift = 0;
+  if (s->is_first) {
+    uint8_t l0 = 0;
+    HIPCHECK(hipMemcpy(&l0, s->bs_start + (size_t)e0, 1, hipMemcpyDeviceToHost));
+    s->init_shift = S.h_init_len[l0];
+  }
+  s->out_len = s->hflags.total_len + s->init_shift;
+  *out_len = s->out_len;
+  return 0;
+}
+
+int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
+  if (!s) return setErr(KX_E_ARG, "null argument");
+  kx_program* p = s->prog; Stage& S = *s->st;
+  if (cap < s->out_len || (s->out_len && !d_out)) return setErr(KX_E_CAPACITY, "output buffer too small");
+  s->stats.out_bytes = s->out_len;
+  if (s->n == 0) {
+    if (s->init_shift) {
+      uint32_t leaf = s->hflags.first_merged;
+      HIPCHECK(hipMemcpyAsync(d_out, S.h_pool.data() + S.h_init_off[leaf], s->init_shift, hipMemcpyHostToDevice, s->stream));
+      HIPCHECK(hipStreamSynchronize(s->stream));
+    }
+    return 0;
+  }
+  const uint32_t bt = p->cfg.block_threads;
+  const uint32_t grid = (s->nblk + bt - 1) / bt;
+  const bool timing = p->cfg.collect_timing;
+  if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
+  hipLaunchKernelGGL(k_emit, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk, s->E,
+                     s->len, s->off, s->bs_start, s->Lc, s->is_first, (uint8_t*)d_out, S.T);
+  if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(s->stream));
+  if (timing) s->stats.kernel_ms[KX_K_EMIT] = evMs(p->ev[0], p->ev[1]);
+  return 0;
+}
+
+void kx_shard_stats(kx_shard* s, kx_stats* st) {
+  if (!s || !st) return;
+  *st = s->stats;
+  st->fail_pos = s->hflags.fail_pos; st->fail_stage = s->stage;
+}
+
+void kx_shard_end(kx_shard* s) {
+  if (!s) return;
+  if (s->prog->live == s) s->prog->live = nullptr;
+  delete s;
+}
+
+// whole program on one device: every stage is a single shard that is both first and last
+static int runPipeline(kx_program* p, const void* d_in, size_t n, void* d_out, size_t cap, bool alloc_final,
+                       void** d_final, size_t* out_len, kx_stats* stats, void* stream) {
+  kx_stats total{}; total.fail_pos = NOFAIL; total.in_bytes = n;
+  const void* cur = d_in; size_t curn = n;
+  void* aligned_copy = nullptr;
+  if (n && ((uintptr_t)d_in & 15)) {  // engine wants 16-byte aligned pieces
+    HIPCHECK(hipMalloc(&aligned_copy, n));
+    HIPCHECK(hipMemcpyAsync(aligned_copy, d_in, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    cur = aligned_copy;
+  }
+  int rc = 0;
+  const uint32_t ns = (uint32_t)p->stages.size();
+  for (uint32_t st = 0; st < ns && rc == 0; ++st) {
+    kx_shard* s = nullptr;
+    rc = kx_shard_begin(p, st, cur, curn, 1, 1, stream, &s);
+    if (rc) break;
+    kx_fwd_summary fs; kx_bwd_summary bs; uint64_t ol = 0;
+    rc = kx_shard_forward(s, &fs);
+    if (!rc) rc = kx_shard_fix_head(s, 0, &fs);
+    if (!rc && fs.fail_pos != NOFAIL) { total.fail_pos = fs.fail_pos; total.fail_stage = st; rc = KX_MATCH_ERROR; }
+    if (!rc) rc = kx_shard_backward(s, &bs);
+    if (!rc) rc = kx_shard_resolve(s, 0, &ol);
+    if (!rc) {
+      void* dst = nullptr; size_t dcap = 0;
+      if (st + 1 == ns) {
+        *out_len = ol;
+        if (alloc_final) {
+          if (hipMalloc(d_final, ol ? ol : 16) != hipSuccess) rc = setErr(KX_E_HIP, "hipMalloc(output) failed");
+          dst = *d_final; dcap = ol;
+        } else {
+          if (ol > cap || (ol && !d_out)) rc = setErr(KX_E_CAPACITY, "output buffer too small");
+          dst = d_out; dcap = cap;
+        }
+      } else {
+        int slot = st & 1;
+        if (p->stagecap[slot] < ol + 16) {
+          if (p->stagebuf[slot]) (void)hipFree(p->stagebuf[slot]);
+          p->stagebuf[slot] = nullptr; p->stagecap[slot] = 0;
+          if (hipMalloc(&p->stagebuf[slot], ol + ol / 8 + 4096) != hipSuccess) rc = setErr(KX_E_HIP, "hipMalloc(stage buffer) failed");
+          else p->stagecap[slot] = ol + ol / 8 + 4096;
+        }
+        dst = p->stagebuf[slot]; dcap = p->stagecap[slot];
+      }
+      if (!rc) rc = kx_shard_emit(s, dst, dcap);
+      if (!rc) { cur = dst; curn = ol; }
+    }
+    kx_stats ss; kx_shard_stats(s, &ss);
+    for (int i = 0; i < KX_NKERNELS; ++i) { total.kernel_ms[i] = ss.kernel_ms[i]; total.total_ms += ss.kernel_ms[i]; }
+    total.unsynced_segments += ss.unsynced_segments;
+    total.out_bytes = ol;
+    kx_shard_end(s);
+  }
+  if (aligned_copy) (void)hipFree(aligned_copy);
+  if (stats) *stats = total;
+  return rc;
+}
+
+int kx_run_device(kx_program* p, const void* d_in, size_t n, void* d_out, size_t cap, size_t* out_len, kx_stats* stats,
+                  void* stream) {
+  if (!p || !out_len) return setErr(KX_E_ARG, "null argument");
+  return runPipeline(p, d_in, n, d_out, cap, false, nullptr, out_len, stats, stream);
+}
+
+int kx_run_host(kx_program* p, const void* in, size_t n, void** out, size_t* out_len, kx_stats* stats) {
+  if (!p || !out || !out_len) return setErr(KX_E_ARG, "null argument");
+  *out = nullptr; *out_len = 0;
+  void* d_in = nullptr; void* d_out = nullptr;
+  if (n) { HIPCHECK(hipMalloc(&d_in, n)); HIPCHECK(hipMemcpy(d_in, in, n, hipMemcpyHostToDevice)); }
+  size_t ol = 0;
+  int rc = runPipeline(p, d_in, n, nullptr, 0, true, &d_out, &ol, stats, nullptr);
+  if (rc == 0) {
+    *out = malloc(ol ? ol : 1);
+    if (!*out) rc = setErr(KX_E_IO, "out of host memory");
+    else if (ol && hipMemcpy(*out, d_out, ol, hipMemcpyDeviceToHost) != hipSuccess) rc = setErr(KX_E_HIP, "D2H copy failed");
+    if (!rc) *out_len = ol;
+  }
+  if (d_out) (void)hipFree(d_out);
+  if (d_in) (void)hipFree(d_in);
+  return rc;
+}
+
+void kx_host_free(void* p) { free(p); }
+
+int kx_run_fd(kx_program* p, int in_fd, int out_fd, kx_stats* stats) {
+  std::vector<char> buf;
+  size_t n = 0;
+  for (;;) {
+    if (buf.size() - n < (1u << 20)) buf.resize(buf.size() ? buf.size() * 2 : (4u << 20));
+    ssize_t r = read(in_fd, buf.data() + n, buf.size() - n);
+    if (r < 0) { if (errno == EINTR) continue; return setErr(KX_E_IO, "read failed"); }
+    if (r == 0) break;
+    n += (size_t)r;
+  }
+  void* out = nullptr; size_t ol = 0;
+  int rc = kx_run_host(p, buf.data(), n, &out, &ol, stats);
+  if (rc == 0) {
+    size_t w = 0;
+    while (w < ol) {
+      ssize_t r = write(out_fd, (char*)out + w, ol - w);
+      if (r < 0) { if (errno == EINTR) continue; free(out); return setErr(KX_E_IO, "write failed"); }
+      w += (size_t)r;
+    }
+  }
+  free(out);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// kxrun.cpp — host driver of a compiled Kleenex binary (`kexc compile … --out BIN`).
+//
+// Keeps the command-line contract of the reference's generated binaries
+// (crt/crt.c:326-467): `BIN < in > out`; `-i` prints compile info and exits 2;
+// `-t` prints "time (ms): N" on stderr; `-h`/unknown prints usage on stdout and
+// exits 1; a rejected input prints "Match error at input symbol <count>!" on
+// stderr and exits 1.  `-p/--phase K` is accepted for compatibility: the phases
+// of a pipeline run as chained device-resident stages inside one process
+// (instead of fork()+pipe(), crt.c:414-454), so a single phase cannot be
+// selected.
+//
+// BIN = this executable ++ KXP blob ++ libdir ++ trailer (see kexc main.cpp).
+// The engine is loaded with dlopen so that this file carries no HIP dependency.
+#include <dlfcn.h>
+#include <getopt.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/kxhip.h"
+
+static void usage(const char* name) {
+  fprintf(stdout, "Normal usage: %s < infile > outfile\n", name);
+  fprintf(stdout, "- \"%s\": reads from stdin and writes to stdout.\n", name);
+  fprintf(stdout, "- \"%s -i\": prints compilation info.\n", name);
+  fprintf(stdout, "- \"%s -t\": runs normally, but prints timing to stderr.\n", name);
+}
+
+int main(int argc, char** argv) {
+  // locate the payload appended to this executable
+  FILE* self = fopen("/proc/self/exe", "rb");
+  if (!self) { perror("/proc/self/exe"); return 1; }
+  fseek(self, 0, SEEK_END);
+  long size = ftell(self);
+  char trailer[24];
+  if (size < 24 || fseek(self, size - 24, SEEK_SET) || fread(trailer, 1, 24, self) != 24 || memcmp(trailer + 16, "KXRUNTRL", 8)) {
+    fprintf(stderr, "%s: no compiled program attached (use `kexc compile prog.kex --out BIN`)\n", argv[0]);
+    return 1;
+  }
+  uint64_t bl, dl;
+  memcpy(&bl, trailer, 8); memcpy(&dl, trailer + 8, 8);
+  std::vector<unsigned char> blob(bl);
+  std::string libdir(dl, '\0');
+  fseek(self, size - 24 - (long)dl - (long)bl, SEEK_SET);
+  if (fread(blob.data(), 1, bl, self) != bl || fread(&libdir[0], 1, dl, self) != dl) { fprintf(stderr, "corrupt payload\n"); return 1; }
+  fclose(self);
+
+  static struct option long_options[] = {{"phase", required_argument, 0, 'p'}, {0, 0, 0, 0}};
+  bool timing = false;
+  int c;
+  while ((c = getopt_long(argc, argv, "ihtp:", long_options, nullptr)) != -1) {
+    switch (c) {
+      case 'i': {
+        uint32_t il; memcpy(&il, blob.data() + 16, 4);
+        std::string info((const char*)blob.data() + 20, il);
+        for (size_t p; (p = info.find("\\n")) != std::string::npos;) info.replace(p, 2, "\n");
+        fprintf(stdout, "%s\n", info.c_str());
+        return 2;
+      }
+      case 't': timing = true; break;
+      case 'p': break;
+      case 'h':
+      default: usage(argv[0]); return 1;
+    }
+  }
+  struct timeval t0, t1;
+  if (timing) gettimeofday(&t0, nullptr);
+
+  const char* env = getenv("KXHIP_LIB");
+  std::string lib = env ? env : libdir + "/libkxhip.so";
+  void* h = dlopen(lib.c_str(), RTLD_NOW);
+  if (!h) { fprintf(stderr, "%s: cannot load the HIP engine: %s\n", argv[0], dlerror()); return 1; }
+  auto load = (int (*)(const void*, size_t, kx_program**))dlsym(h, "kx_load");
+  auto run = (int (*)(kx_program*, int, int, kx_stats*))dlsym(h, "kx_run_fd");
+  auto lasterr = (const char* (*)(void))dlsym(h, "kx_last_error");
+  if (!load || !run || !lasterr) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
+  kx_program* prog = nullptr;
+  if (load(blob.data(), blob.size(), &prog)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
+  kx_stats st;
+  int rc = run(prog, STDIN_FILENO, STDOUT_FILENO, &st);
+  if (rc == KX_MATCH_ERROR) { fprintf(stderr, "Match error at input symbol %zu!\n", (size_t)st.fail_pos); return 1; }
+  if (rc) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
+  if (timing) {
+    gettimeofday(&t1, nullptr);
+    long ms = (t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_usec - t0.tv_usec) / 1000;
+    fprintf(stderr, "time (ms): %ld\n", ms);
+  }
+  return 0;
+}

@@ -1,0 +1,325 @@
+"""ctypes bindings over the two C ABIs (include/kexc_api.h, include/kxhip.h).
+
+Python here is plumbing only: it loads the in-tree shared libraries, moves
+pointers around and mirrors the error behaviour of the reference's produced
+binaries (``Match error at input symbol N!``, exit code 1 — Backends/C.hs:79-81).
+There is no CPU fallback: if ``libkxhip.so`` is missing or no HIP device is
+present, constructing a :class:`Program` raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD_DIR = os.path.join(_HERE, "_build")
+PROGRAM_DIR = os.path.join(_HERE, "programs")
+
+KX_NKERNELS = 6
+KERNEL_NAMES = ("sync", "forward", "head", "backlen", "resolve", "emit")
+KX_MAX_LEAVES = 256
+NOFAIL = 0xFFFFFFFFFFFFFFFF
+
+
+class KleenexError(RuntimeError):
+    pass
+
+
+class CompileError(KleenexError):
+    pass
+
+
+class EngineError(KleenexError):
+    pass
+
+
+class MatchError(KleenexError):
+    """The input is not in the program's language (reference: exit 1 + stderr message)."""
+
+    def __init__(self, pos, stage=0):
+        super().__init__("Match error at input symbol %d!" % pos)
+        self.pos = pos
+        self.stage = stage
+
+
+class KxStats(ctypes.Structure):
+    _fields_ = [("fail_pos", ctypes.c_uint64), ("fail_stage", ctypes.c_uint32),
+                ("unsynced_segments", ctypes.c_uint32), ("in_bytes", ctypes.c_uint64),
+                ("out_bytes", ctypes.c_uint64), ("kernel_ms", ctypes.c_float * KX_NKERNELS),
+                ("total_ms", ctypes.c_float)]
+
+    def as_dict(self):
+        return {"unsynced_segments": self.unsynced_segments, "in_bytes": self.in_bytes,
+                "out_bytes": self.out_bytes, "total_ms": self.total_ms,
+                "kernel_ms": {k: self.kernel_ms[i] for i, k in enumerate(KERNEL_NAMES)}}
+
+
+class KxConfig(ctypes.Structure):
+    _fields_ = [("segment_bytes", ctypes.c_uint32), ("block_threads", ctypes.c_uint32),
+                ("collect_timing", ctypes.c_uint32)]
+
+
+class KxFwdSummary(ctypes.Structure):
+    _fields_ = [("synced", ctypes.c_uint32), ("end_state", ctypes.c_uint32),
+                ("head_len", ctypes.c_uint64), ("fail_pos", ctypes.c_uint64)]
+
+
+class KxBwdSummary(ctypes.Structure):
+    _fields_ = [("constant", ctypes.c_uint32), ("nleaves", ctypes.c_uint32),
+                ("start_leaf", ctypes.c_uint8 * KX_MAX_LEAVES)]
+
+
+_kexc = None
+_kxhip = None
+
+
+def _lib_path(name):
+    return os.path.join(BUILD_DIR, name)
+
+
+def load_compiler():
+    """dlopen libkexc.so (built by ``kleenexlang_amd.build`` / ``__graft_entry__.build``)."""
+    global _kexc
+    if _kexc is None:
+        path = _lib_path("libkexc.so")
+        if not os.path.exists(path):
+            raise CompileError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        lib = ctypes.CDLL(path)
+        lib.kexc_compile.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        lib.kexc_emit_c.argtypes = lib.kexc_compile.argtypes
+        lib.kexc_last_error.restype = ctypes.c_char_p
+        lib.kexc_free.argtypes = [ctypes.c_void_p]
+        _kexc = lib
+    return _kexc
+
+
+def load_engine():
+    """dlopen libkxhip.so; raises if it has not been built (no fallback)."""
+    global _kxhip
+    if _kxhip is None:
+        path = _lib_path("libkxhip.so")
+        if not os.path.exists(path):
+            raise EngineError("HIP engine %s is missing: build it with __graft_entry__.build(); "
+                              "there is no CPU fallback" % path)
+        lib = ctypes.CDLL(path)
+        vp, sz, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
+        lib.kx_load.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+        lib.kx_free.argtypes = [vp]
+        lib.kx_last_error.restype = ctypes.c_char_p
+        lib.kx_set_config.argtypes = [vp, ctypes.POINTER(KxConfig)]
+        lib.kx_num_stages.argtypes = [vp]
+        lib.kx_num_stages.restype = u32
+        lib.kx_run_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(KxStats), vp]
+        lib.kx_run_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz),
+                                    ctypes.POINTER(KxStats)]
+        lib.kx_host_free.argtypes = [vp]
+        lib.kx_run_fd.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(KxStats)]
+        lib.kx_shard_begin.argtypes = [vp, u32, vp, sz, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]
+        lib.kx_shard_forward.argtypes = [vp, ctypes.POINTER(KxFwdSummary)]
+        lib.kx_shard_fix_head.argtypes = [vp, u32, ctypes.POINTER(KxFwdSummary)]
+        lib.kx_shard_backward.argtypes = [vp, ctypes.POINTER(KxBwdSummary)]
+        lib.kx_shard_resolve.argtypes = [vp, u32, ctypes.POINTER(u64)]
+        lib.kx_shard_emit.argtypes = [vp, vp, sz]
+        lib.kx_shard_stats.argtypes = [vp, ctypes.POINTER(KxStats)]
+        lib.kx_shard_end.argtypes = [vp]
+        _kxhip = lib
+    return _kxhip
+
+
+# ------------------------------------------------------------------ compile
+def compile_source(source, name="<memory>", opt=3):
+    """Kleenex source text → KXP blob (bytes).  Mirrors ``kexc compile --opt N`` (direct mode)."""
+    lib = load_compiler()
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    blob = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    rc = lib.kexc_compile(source, len(source), name.encode(), opt, ctypes.byref(blob), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return ctypes.string_at(blob, n.value)
+    finally:
+        lib.kexc_free(blob)
+
+
+def emit_c(source, name="<memory>", opt=3):
+    """``--backend=c``: reference-shaped C text for the CPU baseline."""
+    lib = load_compiler()
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    txt = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    rc = lib.kexc_emit_c(source, len(source), name.encode(), opt, ctypes.byref(txt), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return ctypes.string_at(txt, n.value).decode("utf-8")
+    finally:
+        lib.kexc_free(txt)
+
+
+def program_path(name):
+    p = os.path.join(PROGRAM_DIR, name if name.endswith(".kex") else name + ".kex")
+    if not os.path.exists(p):
+        raise FileNotFoundError(p)
+    return p
+
+
+def compile_file(path, opt=3):
+    if not os.path.exists(path):
+        path = program_path(path)
+    with open(path, "rb") as f:
+        return compile_source(f.read(), os.path.basename(path), opt)
+
+
+# ------------------------------------------------------------------- engine
+class Program:
+    """A compiled Kleenex program loaded on the current HIP device."""
+
+    def __init__(self, blob, segment_bytes=0, block_threads=0, collect_timing=False):
+        self._lib = load_engine()
+        self._h = ctypes.c_void_p()
+        self._blob = bytes(blob)
+        rc = self._lib.kx_load(self._blob, len(self._blob), ctypes.byref(self._h))
+        if rc:
+            raise EngineError(self._err())
+        self.configure(segment_bytes, block_threads, collect_timing)
+        self.last_stats = None
+
+    @classmethod
+    def from_file(cls, path, opt=3, **kw):
+        return cls(compile_file(path, opt), **kw)
+
+    @classmethod
+    def from_source(cls, source, opt=3, **kw):
+        return cls(compile_source(source, opt=opt), **kw)
+
+    def _err(self):
+        return self._lib.kx_last_error().decode("utf-8", "replace")
+
+    def configure(self, segment_bytes=0, block_threads=0, collect_timing=False):
+        cfg = KxConfig(segment_bytes, block_threads, 1 if collect_timing else 0)
+        if self._lib.kx_set_config(self._h, ctypes.byref(cfg)):
+            raise EngineError(self._err())
+
+    @property
+    def num_stages(self):
+        return self._lib.kx_num_stages(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.kx_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, stats):
+        self.last_stats = stats
+        if rc == 1:
+            raise MatchError(stats.fail_pos, stats.fail_stage)
+        if rc:
+            raise EngineError(self._err())
+
+    def run_host(self, data):
+        """bytes → bytes through H2D / engine / D2H."""
+        data = bytes(data)
+        out = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        stats = KxStats()
+        rc = self._lib.kx_run_host(self._h, data, len(data), ctypes.byref(out), ctypes.byref(n), ctypes.byref(stats))
+        try:
+            self._check(rc, stats)
+            return ctypes.string_at(out, n.value)
+        finally:
+            if out.value:
+                self._lib.kx_host_free(out)
+
+    def run_device(self, d_in, n, d_out, cap, stream=None):
+        """Raw device pointers (ints).  Returns the output length; raises MatchError on rejection."""
+        ol = ctypes.c_size_t()
+        stats = KxStats()
+        rc = self._lib.kx_run_device(self._h, ctypes.c_void_p(d_in), n, ctypes.c_void_p(d_out), cap,
+                                     ctypes.byref(ol), ctypes.byref(stats), ctypes.c_void_p(stream or 0))
+        if rc == -3:
+            self.last_stats = stats
+            raise EngineError("output buffer too small: need %d bytes" % ol.value)
+        self._check(rc, stats)
+        return ol.value
+
+    def run_tensor(self, t, out=None):
+        """torch uint8 CUDA tensor → torch uint8 CUDA tensor (device-resident both ends)."""
+        import torch
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+        n = t.numel()
+        if out is None:
+            out = torch.empty(self.out_capacity(n), dtype=torch.uint8, device=t.device)
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        ol = self.run_device(t.data_ptr(), n, out.data_ptr(), out.numel(), stream)
+        return out[:ol]
+
+    def out_capacity(self, n, factor=None):
+        """A generous output allocation for n input bytes (callers may also size exactly via shards)."""
+        f = factor if factor is not None else 8
+        return int(n * f) + 65536
+
+    # sharded protocol (one shard per rank); thin wrappers, see include/kxhip.h
+    def shard_begin(self, stage, d_in, n, is_first, is_last, stream=None):
+        return Shard(self, stage, d_in, n, is_first, is_last, stream)
+
+
+class Shard:
+    def __init__(self, prog, stage, d_in, n, is_first, is_last, stream=None):
+        self._p = prog
+        self._lib = prog._lib
+        self._h = ctypes.c_void_p()
+        rc = self._lib.kx_shard_begin(prog._h, stage, ctypes.c_void_p(d_in), n, int(is_first), int(is_last),
+                                      ctypes.c_void_p(stream or 0), ctypes.byref(self._h))
+        if rc:
+            raise EngineError(prog._err())
+
+    def _ck(self, rc):
+        if rc:
+            raise EngineError(self._p._err())
+
+    def forward(self):
+        s = KxFwdSummary()
+        self._ck(self._lib.kx_shard_forward(self._h, ctypes.byref(s)))
+        return s
+
+    def fix_head(self, incoming_state):
+        s = KxFwdSummary()
+        self._ck(self._lib.kx_shard_fix_head(self._h, incoming_state, ctypes.byref(s)))
+        return s
+
+    def backward(self):
+        s = KxBwdSummary()
+        self._ck(self._lib.kx_shard_backward(self._h, ctypes.byref(s)))
+        return s
+
+    def resolve(self, end_leaf):
+        n = ctypes.c_uint64()
+        self._ck(self._lib.kx_shard_resolve(self._h, end_leaf, ctypes.byref(n)))
+        return n.value
+
+    def emit(self, d_out, cap):
+        self._ck(self._lib.kx_shard_emit(self._h, ctypes.c_void_p(d_out), cap))
+
+    def stats(self):
+        s = KxStats()
+        self._lib.kx_shard_stats(self._h, ctypes.byref(s))
+        return s
+
+    def end(self):
+        if self._h.value:
+            self._lib.kx_shard_end(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass

@@ -100,6 +100,14 @@ def load_engine():
         if not os.path.exists(path):
             raise EngineError("HIP engine %s is missing: build it with __graft_entry__.build(); "
                               "there is no CPU fallback" % path)
+        try:
+            # torch wheels bundle their own libamdhip64.so.7; /opt/rocm ships one with the same soname.
+            # Whichever is mapped first serves the whole process, and torch cannot initialise on the
+            # other one — so inside a torch process let torch's runtime load first.  (C consumers such
+            # as kxrun simply get the system runtime.)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(path)
         vp, sz, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
         lib.kx_load.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]

@@ -1,0 +1,187 @@
+"""GPU: parity of the HIP engine (through the C ABI) with the CPU oracle — bit-exact, always."""
+import hashlib
+import os
+
+import pytest
+from conftest import GOLDEN, blob_of, line_expected, line_input, same_modulo_trailing_newlines
+
+from kleenexlang_amd import MatchError, Program, workloads
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def both(blob, data, **cfg):
+    """(engine result, oracle result) where a result is bytes or ('fail', pos)."""
+    try:
+        want = oracle.run(blob, data)
+    except oracle.OracleMatchError as e:
+        want = ("fail", e.pos)
+    p = Program(blob, **cfg)
+    try:
+        got = p.run_host(data)
+    except MatchError as e:
+        got = ("fail", e.pos)
+    finally:
+        p.close()
+    return got, want
+
+
+def test_loaded_library_is_the_in_tree_hip_engine():
+    from kleenexlang_amd import host
+    host.load_engine()
+    maps = open("/proc/self/maps").read()
+    assert os.path.join(host.BUILD_DIR, "libkxhip.so") in maps
+
+
+@pytest.mark.parametrize("seg", [64, 4096])
+def test_reference_vectors(vectors, seg):
+    for t in vectors["line_tests"]:
+        p = Program(blob_of(t["program"], 0), segment_bytes=seg)
+        got = p.run_host(line_input(t["in"]))
+        assert same_modulo_trailing_newlines(got, line_expected(t["out"])), t["name"]
+        p.close()
+    for t in vectors["exact_tests"]:
+        p = Program(blob_of(t["program"], 3), segment_bytes=seg)
+        for inp, out in t["cases"]:
+            assert p.run_host(inp.encode("utf-8")) == out.encode("utf-8"), (t["name"], inp)
+        p.close()
+
+
+def test_reference_samples_and_seeded_goldens(expected):
+    for prog, e in expected["samples"].items():
+        data = open(os.path.join(GOLDEN, e["input"]), "rb").read()
+        p = Program(blob_of(prog))
+        got = p.run_host(data)
+        assert hashlib.sha256(got).hexdigest() == e["expected"]["sha256"], prog
+        p.close()
+    for e in expected["synthetic"]:
+        data = workloads.generate(workloads.PROGRAM_INPUT[e["program"]], e["nbytes"], e["seed"])
+        p = Program(blob_of(e["program"]))
+        assert hashlib.sha256(p.run_host(data)).hexdigest() == e["expected"]["sha256"], e
+        p.close()
+
+
+@pytest.mark.parametrize("prog", ["apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"])
+@pytest.mark.parametrize("seg", [64, 192, 4096, 65536])
+def test_workloads_vs_oracle_across_segment_sizes(prog, seg):
+    blob = blob_of(prog)
+    for n, seed in [(3000, 11), (200000, 12), (2500000, 13)]:
+        data = workloads.generate(workloads.PROGRAM_INPUT[prog], n, seed)
+        got, want = both(blob, data, segment_bytes=seg)
+        assert got == want, (prog, seg, n)
+
+
+def test_ragged_sizes_around_piece_and_segment_boundaries():
+    blob = blob_of("flip_ab")
+    base = (b"abba\nbab\n" * 2000)
+    for n in [0, 1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 4095, 4096, 4097, 8191, 8192, 8193, 12345]:
+        for seg in (64, 128, 4096):
+            got, want = both(blob, base[:n], segment_bytes=seg)
+            assert got == want, (n, seg)
+
+
+def test_empty_input_and_initial_output():
+    assert both(blob_of("apache_log"), b"")[0] == b"[]\n"
+    assert both(blob_of("flip_ab"), b"")[0] == b""
+    got, want = both(blob_of("main := /ab/"), b"")
+    assert got == want == ("fail", 0)
+
+
+def test_match_error_positions():
+    blob = blob_of("apache_log")
+    good = workloads.generate("apache_log", 300000, 21)
+    for cut in [1, 50, 4096, 70000, 299000]:
+        bad = bytearray(good)
+        bad[cut] = 0          # NUL never matches inside a log line... unless inside a quoted string
+        got, want = both(blob, bytes(bad), segment_bytes=4096)
+        assert got == want, cut
+    for cut in [0, 10, 5000, 131072, len(good) - 1]:   # truncated input: end of input in a non-final state
+        got, want = both(blob, good[:cut], segment_bytes=4096)
+        assert got == want, cut
+    got, want = both(blob_of("flip_ab"), b"ab" * 100000 + b"x" + b"ab" * 50, segment_bytes=64)
+    assert got == want == ("fail", 200000)
+
+
+def test_config1_add_commas_unbounded_registers_on_gpu():
+    """The register form parks MiBs here (SURVEY §7 'unbounded registers'); the path form does not care."""
+    blob = blob_of("add_commas")
+    for term in (True, False):
+        d = workloads.digits(1 << 20, terminated=term)
+        got, want = both(blob, d, segment_bytes=1024)
+        assert got == want
+    mixed = (b"x1234567y99\n" * 30000)
+    assert both(blob, mixed, segment_bytes=256)[0] == oracle.run(blob, mixed)
+
+
+def test_never_synchronising_program_falls_back_to_chaining():
+    """Parity of the number of a's decides the output: segment starts never synchronise."""
+    src = 'main := even\neven := ~/a/ odd | /b/ even | "E" /\\n/\nodd := ~/a/ even | ~/b/ odd | "O" /\\n/\n'
+    blob = blob_of(src)
+    data = b"ab" * 5000 + b"a\n"
+    p = Program(blob, segment_bytes=64)
+    got = p.run_host(data)
+    assert got == oracle.run(blob, data)
+    assert p.last_stats.unsynced_segments > 0
+    p.close()
+
+
+def test_many_simultaneous_paths():
+    blob = blob_of("main := /(a?){32}a{32}\\n/")     # 34 leaves: exercises the wide candidate kernel
+    data = b"a" * 40 + b"\n"
+    assert both(blob, data)[0] == data
+    assert both(blob, b"a" * 31 + b"\n")[0] == ("fail", 31)
+
+
+def test_multi_stage_pipeline_on_device():
+    src = 'start: p >> a >> b\np := (~/abc/ "a")*\na := (/./ "b")*\nb := (/ab/ "c" | ~/[^ab]/ "lol")*\n'
+    blob = blob_of(src)
+    data = b"abc" * 10000
+    got, want = both(blob, data, segment_bytes=128)
+    assert got == want and len(got) == 30000
+
+
+def test_device_resident_full_size_config2_tiled_property():
+    """BASELINE config 2 at full size: 1 GiB apache_log, checked on the GPU against the tiled
+    expectation derived from the oracle's output on one base chunk (no CPU pass over 1 GiB)."""
+    import torch
+    blob = blob_of("apache_log")
+    t, base, k = workloads.device_input("apache_log", 1 << 30, "cuda:0", base_bytes=8 << 20)
+    want = workloads.tiled_expected("apache_log", oracle.run(blob, base), k)
+    p = Program(blob)
+    out = p.run_tensor(t)
+    torch.cuda.synchronize()
+    assert out.numel() == len(want)
+    exp = torch.frombuffer(bytearray(want), dtype=torch.uint8).to("cuda:0")
+    assert bool(torch.equal(out, exp))
+    p.close()
+
+
+def test_device_resident_csv_and_datetime_tiled_property():
+    import torch
+    for prog in ("csv2json", "iso_datetime_to_json"):
+        blob = blob_of(prog)
+        t, base, k = workloads.device_input(prog, 256 << 20, "cuda:0", base_bytes=4 << 20)
+        one = oracle.run(blob, base)
+        p = Program(blob)
+        out = p.run_tensor(t)
+        torch.cuda.synchronize()
+        assert out.numel() == len(one) * k
+        exp = torch.frombuffer(bytearray(one), dtype=torch.uint8).to("cuda:0")
+        assert bool(torch.equal(out.view(k, len(one)), exp.expand(k, len(one))))
+        p.close()
+
+
+def test_produced_binary_stdin_stdout_contract(tmp_path):
+    """kexc compile --out BIN; BIN < in > out ; -t ; rejection message + exit code."""
+    import subprocess
+    from kleenexlang_amd import build, program_path
+    exe = tmp_path / "apache"
+    r = subprocess.run([os.path.join(build.OUT, "kexc"), "compile", "--quiet", program_path("apache_log"), "--out", str(exe)])
+    assert r.returncode == 0
+    data = workloads.generate("apache_log", 500000, 5)
+    r = subprocess.run([str(exe), "-t"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == oracle.run(blob_of("apache_log"), data)
+    assert b"time (ms): " in r.stderr
+    r = subprocess.run([str(exe)], input=data[:1000], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stdout == b"" and r.stderr.endswith(b"Match error at input symbol 1000!\n")

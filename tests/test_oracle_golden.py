@@ -1,0 +1,113 @@
+"""CPU: pin the oracle (and the compiler restatement behind it) to the reference's own vectors."""
+import hashlib
+import os
+
+import pytest
+from conftest import GOLDEN, blob_of, line_expected, line_input, same_modulo_trailing_newlines
+
+from kleenexlang_amd import CompileError, workloads
+from oracle import oracle
+
+
+def _names(vectors, key):
+    return [t["name"] for t in vectors[key]]
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+@pytest.mark.parametrize("path_form", [False, True])
+def test_reference_line_tests(vectors, opt, path_form):
+    for t in vectors["line_tests"]:
+        blob = blob_of(t["program"], opt)
+        got = oracle.run(blob, line_input(t["in"]), path_form=path_form)
+        assert same_modulo_trailing_newlines(got, line_expected(t["out"])), (t["name"], got)
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+@pytest.mark.parametrize("path_form", [False, True])
+def test_reference_exact_tests(vectors, opt, path_form):
+    for t in vectors["exact_tests"]:
+        blob = blob_of(t["program"], opt)
+        for inp, out in t["cases"]:
+            got = oracle.run(blob, inp.encode("utf-8"), path_form=path_form)
+            assert got == out.encode("utf-8"), (t["name"], inp, got)
+
+
+def test_direct_mode_rejects_register_actions(vectors):
+    for t in vectors["direct_mode_rejects"]:
+        with pytest.raises(CompileError, match="action symbols"):
+            blob_of(t["program"])
+
+
+def test_state_counts_match_literal_restatement(vectors):
+    counts = vectors["state_counts"]
+    for t in vectors["line_tests"]:
+        if t["name"] in counts:
+            assert oracle.info(blob_of(t["program"], 0))["nstates"] == counts[t["name"]], t["name"]
+    for prog, n in [("apache_log", 306), ("iso_datetime_to_json", 36), ("csv2json", 23), ("thousand_sep", 6),
+                    ("add_commas", 7), ("flip_ab", 2)]:
+        assert oracle.info(blob_of(prog, 0))["nstates"] == n, prog
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+@pytest.mark.parametrize("path_form", [False, True])
+def test_reference_samples_match_perl_twins(expected, opt, path_form):
+    for prog, e in expected["samples"].items():
+        data = open(os.path.join(GOLDEN, e["input"]), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == e["input_digest"]["sha256"]
+        got = oracle.run(blob_of(prog, opt), data, path_form=path_form)
+        assert len(got) == e["expected"]["bytes"], prog
+        assert hashlib.sha256(got).hexdigest() == e["expected"]["sha256"], prog
+
+
+@pytest.mark.parametrize("path_form", [False, True])
+def test_seeded_synthetic_match_perl_twins(expected, path_form):
+    for e in expected["synthetic"]:
+        data = workloads.generate(workloads.PROGRAM_INPUT[e["program"]], e["nbytes"], e["seed"])
+        assert hashlib.sha256(data).hexdigest() == e["input_digest"]["sha256"], "generator drifted"
+        got = oracle.run(blob_of(e["program"]), data, path_form=path_form)
+        assert hashlib.sha256(got).hexdigest() == e["expected"]["sha256"], (e["program"], e["nbytes"])
+
+
+def _commas(digits):
+    s = digits.decode()
+    head = len(s) % 3 or 3
+    return (s[:head] + "".join("," + s[i:i + 3] for i in range(head, len(s), 3))).encode()
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+def test_config1_add_commas_1mib(opt):
+    """BASELINE config 1: 1 MiB random digits; MiB-sized registers in the register form."""
+    blob = blob_of("add_commas", opt)
+    d = workloads.digits(1 << 20, terminated=True)
+    want = _commas(d[:-1]) + b"\n"
+    assert len(want) == 1398102
+    assert oracle.run(blob, d) == want
+    assert oracle.run(blob, d, path_form=True) == want
+    d2 = workloads.digits(1 << 20, terminated=False)   # the number never completes: identity
+    assert oracle.run(blob, d2) == d2
+    assert oracle.run(blob, d2, path_form=True) == d2
+
+
+def test_match_error_position_and_flush_granularity():
+    blob = blob_of("flip_ab")
+    with pytest.raises(oracle.OracleMatchError) as e:
+        oracle.run(blob, b"abxa\n")
+    assert e.value.pos == 2 and e.value.partial == b"ba"
+    with pytest.raises(oracle.OracleMatchError) as e:   # end of input in a non-final state
+        oracle.run(blob_of("main := /ab/"), b"a")
+    assert e.value.pos == 1
+
+
+def test_reference_runtime_binary_agrees(expected):
+    """oracle/_ref = reference-shaped generated C + the reference's own crt/crt.c (built where the
+    reference tree exists).  It must agree with the restated interpreter byte for byte."""
+    import subprocess
+    exe = oracle.ref_binary("apache_log", 3)
+    if exe is None:
+        pytest.skip("oracle/_ref not built (no reference tree on this machine)")
+    e = expected["samples"]["apache_log"]
+    data = open(os.path.join(GOLDEN, e["input"]), "rb").read()
+    out = subprocess.run([exe], input=data, stdout=subprocess.PIPE, check=True).stdout
+    assert hashlib.sha256(out).hexdigest() == e["expected"]["sha256"]
+    r = subprocess.run([oracle.ref_binary("flip_ab", 3)], input=b"abxa\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stderr == b"Match error at input symbol 2!\n" and r.stdout == b""

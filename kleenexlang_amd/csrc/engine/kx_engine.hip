@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../../include/kxhip.h"
@@ -55,18 +56,23 @@ int setErr(int code, const std::string& m) { g_err = m; return code; }
 constexpr int PIECE = 64;                 // bytes between state checkpoints
 constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
+constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
+constexpr int EMIT_JCAP = 384;            // k_emit: constant-copy jobs per wave round
+constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JCAP * 8;
 
 // ------------------------------------------------------------------ device-side program view
+// States travel as *handles* h = state·C (the word offset of the state's row in `fwd`), so that a
+// transition is one add + one LDS read:  e = fwd[h + cls[byte]] ;  h' = e & 0xFFFF ;  back row = e >> 16.
 struct DevTables {
   const uint32_t* packed;     // [fwd | back_lo | back_hi | pool | cls] — copied verbatim into LDS
   uint32_t packed_words;
   uint32_t off_blo, off_bhi, off_pool, off_cls;  // word offsets inside packed
-  uint32_t nstates, nclasses, q0, maxleaves, dead;
-  const uint8_t* cls;         // global copies for the kernels that do not stage tables
-  const uint8_t* nleaves;     // [nstates+1]
+  uint32_t nstates, nclasses, q0h, maxleaves, deadh, nullrow;
+  const uint8_t* cls;         // global copy for kernels that do not stage the big image
+  const uint8_t* nleaves;     // [nstates+1]  by state id
   const uint8_t* fin_leaf;    // [nstates+1]
-  const uint32_t* sync_next;
-  const uint32_t* sync_state;
+  const uint16_t* sync16;     // [(nsync+1)*C next | (nsync+1) state]: subsets < sync_multi are undecided
+  uint32_t nsync, sync_multi, sync_words;  // sync_words = u32 words of the sync16 image
   const uint32_t* init_off;   // [maxleaves] pool offset / length of the initial closure output
   const uint32_t* init_len;
 };
@@ -86,121 +92,86 @@ __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) 
 
 struct Flags {               // one per shard, device memory
   unsigned long long fail_pos;
-  uint32_t end_state;
+  uint32_t end_state;        // handle of the state entering the byte after the shard
   uint32_t unsynced;
   unsigned long long total_len;
-  uint32_t first_merged;     // lowest block index whose start leaf is independent of its end leaf
+  uint32_t first_merged;
   uint32_t pad;
 };
 
+__device__ __forceinline__ uint32_t byte_at(const uint32_t (&w)[16], int t) { return (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu; }
+// Bit-field extract that the scheduler may not issue before `dep` exists.  The sweeps below are one
+// long dependency chain; without this the compiler unpacks all 64 bytes / 64 offsets of a piece up
+// front and holds them in ~128 VGPRs (measured: 181 VGPRs + scratch vs < 100).
+template <int OFF, int WIDTH>
+__device__ __forceinline__ uint32_t bfe_after(uint32_t word, uint32_t dep) {
+  uint32_t r;
+  asm("v_bfe_u32 %0, %1, %2, %3 ; after %4" : "=v"(r) : "v"(word), "n"(OFF), "n"(WIDTH), "v"(dep));
+  return r;
+}
+#define BYTE_AT_DEP(w, t, dep) bfe_after<((t) & 3) * 8, 8>((w)[(t) >> 2], (dep))
+#define BO_GET_DEP(bo, t, dep) bfe_after<((t) & 1) * 16, 16>((bo)[(t) >> 1], (dep))
+// Make `x` depend on `a` (no instruction emitted): forces side accumulations of a chain step to be
+// retired before the next step instead of keeping every step's table word alive until the end.
+__device__ __forceinline__ void tie(uint32_t& x, uint32_t a) { asm("; tie" : "+v"(x) : "v"(a)); }
+// compile-time step loop: the step index is a constant expression inside the body
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 // ------------------------------------------------------------------------------- k_sync
-// Segment k starts at byte k*seg with an unknown state.  sync_next/sync_state is the subset
-// automaton "set of all states → …" built by the compiler; once it reaches a singleton the state
-// is known no matter what preceded.  Segments that do not converge inside their own bytes are
-// marked UNSYNC and are simply run through by the preceding lane.
+// Segment k starts at byte k*seg with an unknown state.  sync16 is the subset automaton "set of all
+// states → …" built by the compiler, renumbered so that undecided subsets come first and decided
+// ones (singleton / empty / capped) are absorbing: a lane just counts how many steps stay undecided.
+// Segments that do not converge inside their own bytes are marked UNSYNC and are run through by the
+// preceding lane.
+template <bool IN_LDS>
 __global__ void k_sync(const uint8_t* __restrict__ in, uint64_t n, uint64_t seg, uint32_t nseg, int first_known,
                        uint64_t* __restrict__ seg_pos, uint16_t* __restrict__ seg_state, Flags* flags, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint16_t* tab = T.sync16;
+  const uint8_t* cls = T.cls;
+  if (IN_LDS) {
+    const uint32_t* src = (const uint32_t*)T.sync16;
+    for (uint32_t i = threadIdx.x; i < T.sync_words; i += blockDim.x) smem[i] = src[i];
+    const uint32_t* csrc = (const uint32_t*)T.cls;
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) smem[T.sync_words + i] = csrc[i];
+    __syncthreads();
+    tab = (const uint16_t*)smem;
+    cls = (const uint8_t*)(smem + T.sync_words);
+  }
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nseg) return;
-  if (k == 0 && first_known) { seg_pos[0] = 0; seg_state[0] = (uint16_t)T.q0; return; }
+  if (k == 0 && first_known) { seg_pos[0] = 0; seg_state[0] = (uint16_t)T.q0h; return; }
+  const uint32_t C = T.nclasses, M = T.sync_multi;
+  const uint16_t* state_of = tab + (size_t)(T.nsync + 1) * C;
   uint64_t pos = (uint64_t)k * seg;
-  uint64_t limit = pos + seg < n ? pos + seg : n;
-  uint32_t sid = 0;
-  uint32_t st = T.sync_state[0];
-  while (st == KXP_SYNC_MULTI && pos < limit) {
-    sid = T.sync_next[sid * T.nclasses + T.cls[in[pos]]];
-    ++pos;
-    if (sid == KXP_SYNC_UNKNOWN) { st = KXP_SYNC_UNKNOWN; break; }
-    st = T.sync_state[sid];
+  const uint64_t limit = pos + seg < n ? pos + seg : n;
+  uint32_t sid = 0, cnt = 0;
+  while (sid < M && pos + 16 <= limit) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + pos);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      sid = tab[sid * C + cls[(w[b >> 2] >> ((b & 3) * 8)) & 0xFFu]];
+      cnt += sid < M ? 1u : 0u;
+    }
+    pos += 16;
   }
-  if (st < 0xFFFFu) { seg_pos[k] = pos; seg_state[k] = (uint16_t)st; }
+  while (sid < M && pos < limit) {
+    sid = tab[sid * C + cls[in[pos]]];
+    cnt += sid < M ? 1u : 0u;
+    ++pos;
+  }
+  const uint32_t st = sid < M ? 0xFFFFu : state_of[sid];
+  if (st < 0xFFF0u) { seg_pos[k] = (uint64_t)k * seg + cnt + (M ? 1 : 0); seg_state[k] = (uint16_t)(st * C); }
   else { seg_pos[k] = UNSYNC; seg_state[k] = 0; atomicAdd(&flags->unsynced, 1u); }
 }
 
 // ---------------------------------------------------------------------------- k_forward
-// fwd[q*C + c] = next | back_row_offset<<16 ; state `dead` absorbs missing transitions so the
-// hot loop carries no failure branch; the exact position is recovered per 16-byte chunk.
-__device__ __forceinline__ uint32_t byte_of(const uint4& v, int j) {
-  uint32_t w = j < 4 ? v.x : j < 8 ? v.y : j < 12 ? v.z : v.w;
-  return (w >> ((j & 3) * 8)) & 0xFFu;
-}
-
-__global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t nseg,
-                          const uint64_t* __restrict__ seg_pos, const uint16_t* __restrict__ seg_state,
-                          uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nseg) return;
-  uint64_t pos = seg_pos[k];
-  if (pos == UNSYNC) return;
-  uint32_t j = k + 1;
-  while (j < nseg && seg_pos[j] == UNSYNC) ++j;
-  const bool last = j >= nseg;
-  const uint64_t end = last ? n : seg_pos[j];
-  const uint32_t C = T.nclasses, dead = T.dead;
-  uint32_t q = seg_state[k];
-  bool failed = false;
-  while (pos < end && (pos & 15)) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
-    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
-    if (nq == dead) { failed = true; break; }
-    q = nq; ++pos;
-  }
-  while (!failed && pos + 16 <= end) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
-    const uint4 v = *reinterpret_cast<const uint4*>(in + pos);
-    uint32_t q0 = q;
-#pragma unroll
-    for (int b = 0; b < 16; ++b) q = L.fwd[q * C + L.cls[byte_of(v, b)]] & 0xFFFFu;
-    if (q == dead) {  // locate the first missing transition inside this chunk
-      q = q0;
-      for (int b = 0; b < 16; ++b) {
-        uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
-        if (nq == dead) break;
-        q = nq; ++pos;
-      }
-      failed = true;
-      break;
-    }
-    pos += 16;
-  }
-  while (!failed && pos < end) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
-    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
-    if (nq == dead) { failed = true; break; }
-    q = nq; ++pos;
-  }
-  if (failed) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
-  if (last) {
-    flags->end_state = q;
-    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)q;
-  }
-}
-
-// sequential run over the head of a shard (bytes before the first synchronised segment)
-__global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head_len, uint32_t q,
-                       uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
-  if (blockIdx.x || threadIdx.x) return;
-  const uint32_t C = T.nclasses, dead = T.dead;
-  for (uint64_t pos = 0; pos < head_len; ++pos) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)q;
-    uint32_t nq = L.fwd[q * C + L.cls[in[pos]]] & 0xFFFFu;
-    if (nq == dead) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
-    q = nq;
-  }
-  if (head_len == n) {
-    flags->end_state = q;
-    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)q;
-  }
-}
-
-// --------------------------------------------------------------- piece helpers (backward sweeps)
-// A piece is 64 input bytes held in 16 VGPRs; forward re-derivation from its checkpoint yields the
-// back-row offset of every step (kept in registers; all loops are fully unrolled so that the
-// arrays are statically indexed and never spill to scratch).
+// The absorbing dead handle stands for "no transition", so the hot loop has no failure branch; the
+// exact position is recovered by re-running the 64-byte piece in which the run died.
 __device__ __forceinline__ void load_piece(const uint8_t* __restrict__ in, uint64_t n, uint64_t pstart, uint32_t (&w)[16]) {
   if (pstart + PIECE <= n) {
     const uint4* p = reinterpret_cast<const uint4*>(in + pstart);
@@ -217,13 +188,133 @@ __device__ __forceinline__ void load_piece(const uint8_t* __restrict__ in, uint6
   }
 }
 
-__device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t q, uint32_t C, const Lds& L, uint32_t (&bo)[PIECE]) {
+__global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t nseg,
+                          const uint64_t* __restrict__ seg_pos, const uint16_t* __restrict__ seg_state,
+                          uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nseg) return;
+  uint64_t pos = seg_pos[k];
+  if (pos == UNSYNC) return;
+  uint32_t j = k + 1;
+  while (j < nseg && seg_pos[j] == UNSYNC) ++j;
+  const bool last = j >= nseg;
+  const uint64_t end = last ? n : seg_pos[j];
+  const uint32_t dead = T.deadh;
+  uint32_t h = seg_state[k];
+  bool failed = false;
+  while (pos < end && (pos & (PIECE - 1))) {
+    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    if (nh == dead) { failed = true; break; }
+    h = nh; ++pos;
+  }
+  while (!failed && pos + PIECE <= end) {
+    chk[pos >> 6] = (uint16_t)h;
+    uint32_t w[16];
+    load_piece(in, n, pos, w);
+    const uint32_t h0 = h;
+    {
+      uint32_t c[8], cn[8];
+      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.cls[BYTE_AT_DEP(w, i, h)]; });
+      static_for<0, PIECE / 8>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < PIECE / 8)
+          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.cls[BYTE_AT_DEP(w, 8 * (g + 1) + i, h)]; });
+        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; h = L.fwd[h + c[i]] & 0xFFFFu; });
+        if constexpr (g + 1 < PIECE / 8)
+          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = cn[i]; });
+      });
+    }
+    if (h == dead) {
+      h = h0;
+      for (int t = 0; t < PIECE; ++t) {
+        uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+        if (nh == dead) break;
+        h = nh; ++pos;
+      }
+      failed = true;
+      break;
+    }
+    pos += PIECE;
+  }
+  while (!failed && pos < end) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
+    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    if (nh == dead) { failed = true; break; }
+    h = nh; ++pos;
+  }
+  if (failed) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
+  if (last) {
+    flags->end_state = h;
+    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)h;
+  }
+}
+
+// sequential run over the head of a shard (bytes before the first synchronised segment)
+__global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head_len, uint32_t h,
+                       uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  if (blockIdx.x || threadIdx.x) return;
+  const uint32_t dead = T.deadh;
+  for (uint64_t pos = 0; pos < head_len; ++pos) {
+    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
+    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    if (nh == dead) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
+    h = nh;
+  }
+  if (head_len == n) {
+    flags->end_state = h;
+    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)h;
+  }
+}
+
+// --------------------------------------------------------------- piece helpers (backward sweeps)
+// A piece is 64 input bytes held in 16 VGPRs; forward re-derivation from its checkpoint yields the
+// back-row offset of every step (kept in registers; all loops are fully unrolled so that the
+// arrays are statically indexed and never spill to scratch).
+// Opaque touch: stops the compiler from keeping per-byte / per-step extractions of a previous phase
+// alive (it would otherwise hold 64+64 unpacked values across the phases and spill to scratch).
+template <int N>
+__device__ __forceinline__ void launder(uint32_t (&a)[N]) {
 #pragma unroll
-  for (int t = 0; t < PIECE; ++t) {
-    uint32_t byte = (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu;
-    uint32_t e = L.fwd[q * C + L.cls[byte]];
-    bo[t] = e >> 16;
-    q = e & 0xFFFFu;
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(a[i]));
+}
+
+// back-row offsets are 16-bit: two steps share a VGPR (keeps the sweeps at 4+ waves per SIMD)
+constexpr int BOW = PIECE / 2;
+__device__ __forceinline__ uint32_t bo_get(const uint32_t (&bo)[BOW], int t) { return (t & 1) ? (bo[t >> 1] >> 16) : (bo[t >> 1] & 0xFFFFu); }
+__device__ __forceinline__ void bo_set(uint32_t (&bo)[BOW], int t, uint32_t v) {
+  bo[t >> 1] = (t & 1) ? ((bo[t >> 1] & 0xFFFFu) | (v << 16)) : ((bo[t >> 1] & 0xFFFF0000u) | v);
+}
+__device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t h, const Lds& L, uint32_t (&bo)[BOW]) {
+  // byte-class lookups do not depend on the state, so they are prefetched one group of 8 ahead of
+  // the dependent fwd[] chain — and no further (all 64 at once would cost 64 VGPRs)
+  uint32_t c[8], cn[8];
+  static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.cls[BYTE_AT_DEP(w, i, h)]; });
+  static_for<0, PIECE / 8>([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    if constexpr (g + 1 < PIECE / 8)
+      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.cls[BYTE_AT_DEP(w, 8 * (g + 1) + i, h)]; });
+    static_for<0, 4>([&](auto ic) {
+      constexpr int i = 2 * decltype(ic)::value;
+      const uint32_t e0 = L.fwd[h + c[i]];
+      h = e0 & 0xFFFFu;
+      const uint32_t e1 = L.fwd[h + c[i + 1]];
+      h = e1 & 0xFFFFu;
+      bo[(8 * g + i) >> 1] = (e0 >> 16) | (e1 & 0xFFFF0000u);
+    });
+    if constexpr (g + 1 < PIECE / 8)
+      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = cn[i]; });
+  });
+}
+// Steps beyond the end of a partial piece point at the identity row (parent = leaf, nothing
+// appended), so the sweeps below need no per-step bounds test.
+__device__ __forceinline__ void mask_tail(uint32_t (&bo)[BOW], int plen, uint32_t nullrow) {
+  if (plen < PIECE) {
+#pragma unroll
+    for (int t = 0; t < PIECE; ++t) if (t >= plen) bo_set(bo, t, nullrow);
   }
 }
 
@@ -231,20 +322,23 @@ __device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t 
 // back_lo[row + leaf] = parent | copy<<8 | (bytes appended on this step)<<9.
 // For block m and every leaf the block could end in: where the path enters the block (start leaf)
 // and how many output bytes the block contributes.  Candidates are advanced piece by piece and
-// collapse to one as soon as they agree.
+// collapse to one as soon as they agree; from there on the per-piece end leaf and the running
+// output length are final and are written out for k_emit (pleaf/pcum).  Pieces above the merge
+// point (the block's tail) are finished by k_fixtail once the block's end leaf is known.
 template <int MAXC>
 __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const Flags* flags, int is_last,
                           uint8_t* __restrict__ bs_start, uint32_t* __restrict__ bs_len, uint8_t* __restrict__ bs_merged,
-                          uint8_t* __restrict__ bs_mstart, uint32_t Lc, DevTables T) {
+                          uint8_t* __restrict__ bs_mstart, uint32_t Lc, uint8_t* __restrict__ pleaf,
+                          int32_t* __restrict__ pcum, uint16_t* __restrict__ merge_piece, uint32_t* __restrict__ ctot,
+                          DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
-  const uint32_t C = T.nclasses;
-  const uint32_t qe = bend == n ? flags->end_state : chk[bend >> 6];
+  const uint32_t qe = (bend == n ? flags->end_state : chk[bend >> 6]) / T.nclasses;
   uint8_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];
   uint32_t nc, nact;
   uint32_t known = 0xFFFFFFFFu;
@@ -253,37 +347,45 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   for (uint32_t j = 0; j < nc; ++j) { clen[j] = 0; pre[j] = 0; }
   nact = nc;
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
+  const uint64_t piece0 = bstart >> 6;
+  uint32_t mp = nact == 1 ? npieces : 0;   // pieces [mp, npieces) form the unresolved tail
   for (uint32_t p = npieces; p-- > 0;) {
     const uint64_t pstart = bstart + (uint64_t)p * PIECE;
     const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
-    uint32_t w[16], bo[PIECE];
+    uint32_t w[16], bo[BOW];
     load_piece(in, n, pstart, w);
-    piece_forward(w, chk[pstart >> 6], C, L, bo);
+    piece_forward(w, chk[pstart >> 6], L, bo);
+    mask_tail(bo, plen, T.nullrow);
+    const bool final_here = nact == 1;
+    if (final_here) pleaf[piece0 + p] = cl[0];
     for (uint32_t j = 0; j < nact; ++j) {
       uint32_t leaf = cl[j], sum = 0;
-#pragma unroll
-      for (int t = PIECE - 1; t >= 0; --t) {
-        if (t < plen) { uint32_t lo = L.blo[bo[t] + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; }
-      }
+      static_for<0, PIECE>([&](auto ic) {
+        constexpr int t = PIECE - 1 - decltype(ic)::value;
+        const uint32_t lo = L.blo[BO_GET_DEP(bo, t, leaf) + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; tie(leaf, sum);
+      });
       cl[j] = (uint8_t)leaf; clen[j] += sum;
     }
-    if (nact > 1) {
+    if (final_here) pcum[piece0 + p] = (int32_t)(clen[0] - pre[0]);
+    else {
       bool same = true;
       for (uint32_t j = 1; j < nact; ++j) same = same && cl[j] == cl[0];
-      if (same) { for (uint32_t j = 0; j < nc; ++j) pre[j] = clen[j]; nact = 1; }
+      if (same) { for (uint32_t j = 0; j < nc; ++j) pre[j] = clen[j]; nact = 1; mp = p; }
     }
   }
   const bool merged = nact == 1;
+  const uint32_t tail = clen[0] - pre[0];
   if (known != 0xFFFFFFFFu) {
     bs_start[(size_t)m * Lc + known] = cl[0]; bs_len[(size_t)m * Lc + known] = clen[0];
   } else if (merged) {  // after merging only candidate 0 kept accumulating
-    const uint32_t tail = clen[0] - pre[0];
     for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[0]; bs_len[(size_t)m * Lc + j] = pre[j] + tail; }
   } else {
     for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[j]; bs_len[(size_t)m * Lc + j] = clen[j]; }
   }
   bs_merged[m] = merged ? 1 : 0;
   bs_mstart[m] = cl[0];
+  merge_piece[m] = (uint16_t)(merged ? mp : 0);
+  ctot[m] = merged ? tail : 0;
 }
 
 // ---------------------------------------------------------------------------- k_resolve
@@ -293,7 +395,7 @@ __global__ void k_resolve(uint32_t nblk, uint32_t end_leaf, const uint8_t* __res
                           const uint32_t* __restrict__ bs_len, const uint8_t* __restrict__ bs_merged,
                           const uint8_t* __restrict__ bs_mstart, uint32_t Lc, uint8_t* __restrict__ E,
                           uint32_t* __restrict__ len, unsigned long long* __restrict__ wsum) {
-  __shared__ unsigned long long red[256];
+  __shared__ unsigned long long red[1024];
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t mylen = 0;
   if (m < nblk) {
@@ -347,7 +449,7 @@ __global__ void k_scan_groups(uint32_t ngroups, const unsigned long long* __rest
 
 __global__ void k_scan_blocks(uint32_t nblk, const uint32_t* __restrict__ len, const unsigned long long* __restrict__ woff,
                               unsigned long long* __restrict__ off) {
-  __shared__ unsigned long long buf[256];
+  __shared__ unsigned long long buf[1024];
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long v = m < nblk ? len[m] : 0;
   buf[threadIdx.x] = v;
@@ -383,49 +485,169 @@ __global__ void k_shard_map(uint32_t nblk, uint32_t nleaves_end, const uint8_t* 
   }
 }
 
-// ------------------------------------------------------------------------------- k_emit
-// back_hi[row + leaf] = pool offset of the constant appended on that step.  Output is produced
-// back to front inside the block, starting from the block's end offset.
-__global__ void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
-                       const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
-                       const uint32_t* __restrict__ len, const unsigned long long* __restrict__ off,
-                       const uint8_t* __restrict__ bs_start, uint32_t Lc, int is_first,
-                       uint8_t* __restrict__ out, DevTables T) {
+// ------------------------------------------------------------------------------ k_fixtail
+// With the block's end leaf E known, walk the unresolved tail pieces [merge_piece, npieces) again
+// and write their end leaf and offset in the convention of k_backlen:
+//   output offset of piece p inside its block = ctot[m] - pcum[p].
+__global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
+                          const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
+                          const uint32_t* __restrict__ len, const uint16_t* __restrict__ merge_piece,
+                          const uint32_t* __restrict__ ctot, uint8_t* __restrict__ pleaf, int32_t* __restrict__ pcum,
+                          DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
-  const uint32_t C = T.nclasses;
-  // the initial closure's output precedes everything on the first shard
-  uint32_t init_shift = 0;
-  if (is_first) init_shift = T.init_len[bs_start[(size_t)0 * Lc + E[0]]];
-  uint64_t o = init_shift + off[m] + len[m];
-  uint32_t leaf = E[m];
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
-  for (uint32_t p = npieces; p-- > 0;) {
+  const uint32_t mp = merge_piece[m];
+  if (mp >= npieces) return;
+  const uint64_t piece0 = bstart >> 6;
+  uint32_t leaf = E[m], suffix = 0;
+  const int32_t base = (int32_t)ctot[m] - (int32_t)len[m];
+  for (uint32_t p = npieces; p-- > mp;) {
     const uint64_t pstart = bstart + (uint64_t)p * PIECE;
     const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
-    uint32_t w[16], bo[PIECE];
+    uint32_t w[16], bo[BOW];
     load_piece(in, n, pstart, w);
-    piece_forward(w, chk[pstart >> 6], C, L, bo);
-#pragma unroll
-    for (int t = PIECE - 1; t >= 0; --t) {
-      if (t < plen) {
-        const uint32_t lo = L.blo[bo[t] + leaf];
-        const uint32_t hi = L.bhi[bo[t] + leaf];
-        const uint32_t copy = (lo >> 8) & 1u;
-        uint32_t cl = (lo >> 9) - copy;
-        while (cl > 0) { --cl; out[--o] = L.pool[hi + cl]; }
-        if (copy) out[--o] = (uint8_t)((w[t >> 2] >> ((t & 3) * 8)) & 0xFFu);
-        leaf = lo & 0xFFu;
-      }
-    }
+    piece_forward(w, chk[pstart >> 6], L, bo);
+    mask_tail(bo, plen, T.nullrow);
+    pleaf[piece0 + p] = (uint8_t)leaf;
+    uint32_t sum = 0;
+    static_for<0, PIECE>([&](auto ic) {
+      constexpr int t = PIECE - 1 - decltype(ic)::value;
+      const uint32_t lo = L.blo[BO_GET_DEP(bo, t, leaf) + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; tie(leaf, sum);
+    });
+    suffix += sum;
+    pcum[piece0 + p] = base + (int32_t)suffix;
   }
-  if (m == 0 && is_first) {
-    const uint32_t io = T.init_off[leaf], il = T.init_len[leaf];
-    for (uint32_t i = 0; i < il; ++i) out[i] = L.pool[io + i];
+}
+
+// ------------------------------------------------------------------------------- k_emit
+// One lane = one 64-byte piece; one wave-iteration = 64 consecutive pieces = 4 KiB of contiguous
+// input and a contiguous stretch of output.  Every lane re-derives its piece, walks it backward
+// from its resolved end leaf, then the wave assembles the output in an LDS staging buffer —
+// copied input bytes by their owning lane, constants by a wave-wide job list (one lane per
+// constant, so that the cost does not depend on which lanes happen to sit on a constant) — and
+// flushes it with aligned 16-byte stores.  Persistent workgroups: tables are staged once per CU.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
+                                                     uint64_t npieces_total, const uint16_t* __restrict__ chk,
+                                                     const uint8_t* __restrict__ pleaf, const int32_t* __restrict__ pcum,
+                                                     const uint32_t* __restrict__ ctot,
+                                                     const unsigned long long* __restrict__ off, uint32_t init_shift,
+                                                     uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Lds L = stage_tables(T, smem);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* stg = (uint8_t*)(smem + ((T.packed_words + 3) & ~3u)) + (size_t)wave * EMIT_WAVE_LDS;
+  uint32_t* jobs = (uint32_t*)(stg + EMIT_STG + 16);
+  if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pool[T.init_off[init_leaf] + threadIdx.x];
+  if (is_first && blockIdx.x == 0 && init_shift > blockDim.x)
+    for (uint32_t i = blockDim.x + threadIdx.x; i < init_shift; i += blockDim.x) out[i] = L.pool[T.init_off[init_leaf] + i];
+  const uint64_t nwi = (npieces_total + 63) / 64;
+  for (uint64_t it = (uint64_t)blockIdx.x * WAVES + wave; it < nwi; it += (uint64_t)gridDim.x * WAVES) {
+    const uint64_t piece = it * 64 + lane;
+    const bool valid = piece < npieces_total;
+    const uint64_t pstart = piece * PIECE;
+    const int plen = valid ? (int)(n - pstart < PIECE ? n - pstart : PIECE) : 0;
+    uint32_t w[16], bo[BOW];
+    uint32_t olen = 0, nj = 0;
+    uint64_t ostart = 0;
+    load_piece(in, n, valid ? pstart : n, w);
+    piece_forward(w, valid ? chk[piece] : T.deadh, L, bo);
+    mask_tail(bo, plen, T.nullrow);
+    {
+      uint32_t leaf = valid ? pleaf[piece] : 0u;
+      static_for<0, PIECE>([&](auto ic) {
+        constexpr int t = PIECE - 1 - decltype(ic)::value;
+        const uint32_t idx = BO_GET_DEP(bo, t, leaf) + leaf;
+        const uint32_t lo = L.blo[idx];
+        bo_set(bo, t, idx);
+        const uint32_t dl = lo >> 9;
+        olen += dl;
+        nj += dl > ((lo >> 8) & 1u) ? 1u : 0u;
+        leaf = lo & 0xFFu;
+        tie(leaf, olen); tie(leaf, nj);
+      });
+    }
+    if (valid) {
+      const uint64_t m = pstart / blk;
+      ostart = (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - pcum[piece]);
+    }
+    // inclusive prefix of the job counts over the wave
+    uint32_t pj = nj;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t x = __shfl_up(pj, d); if ((int)lane >= d) pj += x; }
+    const unsigned long long vmask = __ballot(valid);
+    const uint32_t nvalid = (uint32_t)__popcll(vmask);
+    uint32_t first = 0;
+    while (first < nvalid) {
+      const uint64_t gs = __shfl(ostart, first);
+      const uint64_t abase = gs & ~15ull;
+      const uint32_t pj_before = first ? __shfl(pj, first - 1) : 0u;
+      const bool fits = valid && lane >= first && (ostart + olen - abase) <= (uint64_t)EMIT_STG && (pj - pj_before) <= (uint32_t)EMIT_JCAP;
+      const unsigned long long fm = __ballot(fits) >> first;
+      const uint32_t cnt = fm == ~0ull ? 64u - first : (uint32_t)__builtin_ctzll(~fm);   // leading run of fitting lanes
+      if (cnt == 0) {
+        // a single piece larger than the staging area: its lane writes straight to global memory
+        if (lane == first) {
+          uint64_t o = ostart;
+          static_for<0, PIECE>([&](auto ic) {
+            constexpr int t = decltype(ic)::value;
+            const uint32_t idx = BO_GET_DEP(bo, t, (uint32_t)o);
+            const uint32_t lo = L.blo[idx], hi = L.bhi[idx];
+            const uint32_t cp = (lo >> 8) & 1u, cl = (lo >> 9) - cp;
+            if (cp) out[o++] = (uint8_t)BYTE_AT_DEP(w, t, idx);
+            for (uint32_t i = 0; i < cl; ++i) out[o++] = L.pool[hi + i];
+          });
+        }
+        first += 1;
+        continue;
+      }
+      const uint32_t lastl = first + cnt - 1;
+      const bool active = lane >= first && lane <= lastl;
+      launder(w); launder(bo);
+      // phase 1: copied bytes into staging, constants into the job list
+      if (active) {
+        uint32_t o = (uint32_t)(ostart - abase);
+        uint32_t ji = (pj - nj) - pj_before;
+        static_for<0, PIECE>([&](auto ic) {
+          constexpr int t = decltype(ic)::value;
+          const uint32_t idx = BO_GET_DEP(bo, t, o);
+          const uint32_t lo = L.blo[idx];
+          const uint32_t cp = (lo >> 8) & 1u, dl = lo >> 9;
+          if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, idx);
+          if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = L.bhi[idx]; ++ji; }
+          o += dl;
+        });
+      }
+      wave_lds_fence();
+      // phase 2: one lane per constant
+      const uint32_t njobs = __shfl(pj, lastl) - pj_before;
+      for (uint32_t j = lane; j < njobs; j += 64) {
+        const uint32_t a = jobs[2 * j], src = jobs[2 * j + 1];
+        const uint32_t d = a & 0xFFFFu, l = a >> 16;
+        for (uint32_t i = 0; i < l; ++i) stg[d + i] = L.pool[src + i];
+      }
+      wave_lds_fence();
+      // flush [gs, ge): partial head and tail windows bytewise, everything between as aligned 16 B
+      const uint64_t ge = __shfl(ostart + olen, lastl);
+      const uint64_t fs = (gs + 15) & ~15ull, fe = ge & ~15ull;
+      if (fs >= fe) {
+        for (uint64_t x = gs + lane; x < ge; x += 64) out[x] = stg[x - abase];
+      } else {
+        if (gs + lane < fs) out[gs + lane] = stg[gs + lane - abase];
+        if (fe + lane < ge) out[fe + lane] = stg[fe + lane - abase];
+        for (uint64_t x = fs + (uint64_t)lane * 16; x < fe; x += 1024)
+          *reinterpret_cast<uint4*>(out + x) = *reinterpret_cast<const uint4*>(stg + (x - abase));
+      }
+      wave_lds_fence();
+      first = lastl + 1;
+    }
   }
 }
 
@@ -437,7 +659,8 @@ struct Stage {
   std::vector<uint8_t> h_pool;
   void* d_all = nullptr;                               // one allocation holding every table
   DevTables T{};
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0;                                // packed table image
+  size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
 };
 
 struct Arena {  // grow-only device workspace, reused across runs
@@ -471,6 +694,8 @@ struct kx_program {
   hipEvent_t ev[KX_NKERNELS + 1] = {};
   bool have_events = false;
   kx_shard* live = nullptr;
+  int ncu = 256;
+  int emit_waves = 4;
 };
 
 struct kx_shard {
@@ -479,10 +704,12 @@ struct kx_shard {
   uint64_t seg; uint32_t nseg, nblk, Lc, ngroups;
   // workspace
   uint64_t* seg_pos; uint16_t* seg_state; uint16_t* chk; Flags* flags;
-  uint8_t *bs_start, *bs_merged, *bs_mstart, *E, *d_map; uint32_t *bs_len, *len, *d_const;
+  uint8_t *bs_start, *bs_merged, *bs_mstart, *E, *d_map, *pleaf; uint32_t *bs_len, *len, *d_const, *ctot;
+  int32_t* pcum; uint16_t* merge_piece;
   unsigned long long *off, *wsum, *woff;
   // control state mirrored on the host
-  Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0;
+  Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0, init_leaf = 0;
+  uint32_t endId() const { return hflags.end_state / st->nclasses; }
   kx_stats stats{};
 };
 
@@ -515,8 +742,8 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t* sync_next = (const uint32_t*)c; c += (size_t)nsync * C * 4;
   const uint32_t* sync_state = (const uint32_t*)c; c += (size_t)nsync * 4;
   if (c > end) return setErr(KX_E_BLOB, "truncated stage body");
-  if (nstates == 0 || nstates >= 0xFFFE || C == 0 || Lm == 0 || Lm > 254)
-    return setErr(KX_E_BLOB, "program outside engine limits (states/leaves)");
+  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C > 0xFFF0)
+    return setErr(KX_E_BLOB, "program outside engine limits (states x classes / leaves)");
 
   S.nstates = nstates; S.nclasses = C; S.q0 = q0; S.maxleaves = Lm;
   // ragged back rows: row b keeps entries up to its last live leaf
@@ -535,18 +762,20 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
       bhi.push_back(pcoff[pc]);
     }
   }
-  // a lane may probe row+leaf for a leaf beyond the row's live range only on a dead path; pad so
-  // that even then it stays inside the table
+  // identity row (parent = leaf, nothing appended): steps past the end of a partial piece point here;
+  // it also pads the table so that a probe on a dead path stays inside it
+  const uint32_t nullrow = (uint32_t)blo.size();
+  for (uint32_t j = 0; j < Lm; ++j) { blo.push_back(j); bhi.push_back(0); }
   for (uint32_t j = 0; j < Lm; ++j) { blo.push_back(0); bhi.push_back(0); }
   if (blo.size() >= 65536) return setErr(KX_E_BLOB, "backward table exceeds 65535 entries");
-  const uint32_t dead = nstates;
+  const uint32_t deadh = nstates * C;                 // handle of the absorbing "no transition" state
   std::vector<uint32_t> fwd((size_t)(nstates + 1) * C);
   for (uint32_t q = 0; q < nstates; ++q)
     for (uint32_t k = 0; k < C; ++k) {
       uint16_t d = delta[(size_t)q * C + k];
-      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? dead : (d | (rowoff[pback[(size_t)q * C + k]] << 16));
+      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? deadh : ((uint32_t)d * C | (rowoff[pback[(size_t)q * C + k]] << 16));
     }
-  for (uint32_t k = 0; k < C; ++k) fwd[(size_t)dead * C + k] = dead;
+  for (uint32_t k = 0; k < C; ++k) fwd[(size_t)nstates * C + k] = deadh;
 
   // packed LDS image: fwd | back_lo | back_hi | pool | cls
   std::vector<uint32_t> packed(fwd);
@@ -569,18 +798,39 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   S.h_init_off.resize(Lm); S.h_init_len.resize(Lm);
   for (uint32_t j = 0; j < Lm; ++j) { S.h_init_off[j] = pcoff[init_const[j]]; S.h_init_len[j] = pcoff[init_const[j] + 1] - pcoff[init_const[j]]; }
 
-  // one device allocation: packed | cls | nleaves | fin_leaf | sync_next | sync_state | init_off | init_len
+  // synchronising automaton, renumbered: undecided subsets first, decided ones absorbing; one extra
+  // absorbing row stands for "subset construction was capped here"
+  if (nsync == 0 || nsync >= 0xFFF0) return setErr(KX_E_BLOB, "bad synchronising automaton");
+  std::vector<uint32_t> newid(nsync);
+  uint32_t nmulti = 0;
+  for (uint32_t i = 0; i < nsync; ++i) if (sync_state[i] == KXP_SYNC_MULTI) newid[i] = nmulti++;
+  { uint32_t t = nmulti; for (uint32_t i = 0; i < nsync; ++i) if (sync_state[i] != KXP_SYNC_MULTI) newid[i] = t++; }
+  std::vector<uint16_t> sync16(((size_t)(nsync + 1) * (C + 1) + 1) & ~(size_t)1, 0);
+  for (uint32_t i = 0; i < nsync; ++i) {
+    const bool multi = sync_state[i] == KXP_SYNC_MULTI;
+    for (uint32_t k = 0; k < C; ++k) {
+      uint32_t nx = sync_next[(size_t)i * C + k];
+      sync16[(size_t)newid[i] * C + k] = (uint16_t)(!multi ? newid[i] : nx == KXP_SYNC_UNKNOWN ? nsync : newid[nx]);
+    }
+    uint32_t st = sync_state[i];
+    sync16[(size_t)(nsync + 1) * C + newid[i]] = (uint16_t)(st == KXP_SYNC_MULTI ? 0xFFFF : st == KXP_SYNC_EMPTY ? 0xFFFE : st);
+  }
+  for (uint32_t k = 0; k < C; ++k) sync16[(size_t)nsync * C + k] = (uint16_t)nsync;
+  sync16[(size_t)(nsync + 1) * C + nsync] = 0xFFFD;
+  const size_t sync_bytes = sync16.size() * 2;
+  S.sync_lds_bytes = sync_bytes + 256 <= 64 * 1024 ? sync_bytes + 256 : 0;
+
+  // one device allocation: packed | cls | nleaves | fin_leaf | sync16 | init_off | init_len
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o_packed = 0, o_cls = o_packed + al(packed.size() * 4), o_nl = o_cls + 256, o_fl = o_nl + al(nstates + 1),
-         o_sn = o_fl + al(nstates + 1), o_ss = o_sn + al((size_t)nsync * C * 4), o_io = o_ss + al((size_t)nsync * 4),
+         o_sn = o_fl + al(nstates + 1), o_io = o_sn + al(sync_bytes),
          o_il = o_io + al(Lm * 4), total = o_il + al(Lm * 4);
   std::vector<uint8_t> img(total, 0);
   memcpy(&img[o_packed], packed.data(), packed.size() * 4);
   memcpy(&img[o_cls], cls, 256);
   memcpy(&img[o_nl], S.h_nleaves.data(), nstates + 1);
   memcpy(&img[o_fl], S.h_fin_leaf.data(), nstates + 1);
-  memcpy(&img[o_sn], sync_next, (size_t)nsync * C * 4);
-  memcpy(&img[o_ss], sync_state, (size_t)nsync * 4);
+  memcpy(&img[o_sn], sync16.data(), sync_bytes);
   memcpy(&img[o_io], S.h_init_off.data(), Lm * 4);
   memcpy(&img[o_il], S.h_init_len.data(), Lm * 4);
   HIPCHECK(hipMalloc(&S.d_all, total));
@@ -589,9 +839,9 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   DevTables& T = S.T;
   T.packed = (const uint32_t*)(d + o_packed); T.packed_words = (uint32_t)packed.size();
   T.off_blo = off_blo; T.off_bhi = off_bhi; T.off_pool = off_pool; T.off_cls = off_cls;
-  T.nstates = nstates; T.nclasses = C; T.q0 = q0; T.maxleaves = Lm; T.dead = dead;
+T.nstates = nstates; T.nclasses = C; T.q0h = q0 * C; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
   T.cls = (const uint8_t*)(d + o_cls); T.nleaves = (const uint8_t*)(d + o_nl); T.fin_leaf = (const uint8_t*)(d + o_fl);
-  T.sync_next = (const uint32_t*)(d + o_sn); T.sync_state = (const uint32_t*)(d + o_ss);
+  T.sync16 = (const uint16_t*)(d + o_sn); T.nsync = nsync; T.sync_multi = nmulti; T.sync_words = (uint32_t)(sync_bytes / 4);
   T.init_off = (const uint32_t*)(d + o_io); T.init_len = (const uint32_t*)(d + o_il);
   return 0;
 }
@@ -627,13 +877,27 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
     int rc = parseStage(c, b + blob_len, p->stages[s]);
     if (rc) { kx_free(p); return rc; }
   }
-  size_t lds = 0;
-  for (auto& s : p->stages) lds = s.lds_bytes > lds ? s.lds_bytes : lds;
+  size_t lds = 0, slds = 0;
+  for (auto& s : p->stages) { lds = s.lds_bytes > lds ? s.lds_bytes : lds; slds = s.sync_lds_bytes > slds ? s.sync_lds_bytes : slds; }
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) p->ncu = prop.multiProcessorCount;
+  // k_emit: as many waves per CU as the LDS left over by the tables allows (one workgroup per CU)
+  const size_t lds_cap = 160 * 1024;
+  const size_t tab = (lds + 15) & ~(size_t)15;
+  p->emit_waves = tab + 16 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 16 : tab + 12 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 12
+                  : tab + 8 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 8 : 4;
+  if (tab + 4 * (size_t)EMIT_WAVE_LDS > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
   int rc = setLds((const void*)k_forward, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_head, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_backlen<32>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_backlen<256>, lds); if (rc) { kx_free(p); return rc; }
-  rc = setLds((const void*)k_emit, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_fixtail, lds); if (rc) { kx_free(p); return rc; }
+  if (slds) { rc = setLds((const void*)k_sync<true>, slds); if (rc) { kx_free(p); return rc; } }
+  const size_t elds = tab + (size_t)p->emit_waves * EMIT_WAVE_LDS;
+  rc = p->emit_waves == 16 ? setLds((const void*)k_emit<16>, elds) : p->emit_waves == 12 ? setLds((const void*)k_emit<12>, elds)
+       : p->emit_waves == 8 ? setLds((const void*)k_emit<8>, elds) : setLds((const void*)k_emit<4>, elds);
+  if (rc) { kx_free(p); return rc; }
   *prog = p;
   return 0;
 }
@@ -652,8 +916,9 @@ int kx_set_config(kx_program* p, const kx_config* cfg) {
   kx_config c = *cfg;
   if (c.segment_bytes == 0) c.segment_bytes = 4096;
   if (c.block_threads == 0) c.block_threads = 256;
-  if (c.segment_bytes % PIECE || c.block_threads % 64 || c.block_threads > 1024)
-    return setErr(KX_E_ARG, "segment_bytes must be a multiple of 64, block_threads a multiple of 64 ≤ 1024");
+  if (c.segment_bytes % PIECE || c.segment_bytes > 65535u * PIECE || c.block_threads % 64 || c.block_threads > 1024 ||
+      (c.block_threads & (c.block_threads - 1)))
+    return setErr(KX_E_ARG, "segment_bytes: multiple of 64 (≤ 4 MiB); block_threads: power of two in [64, 1024]");
   p->cfg = c;
   return 0;
 }
@@ -677,8 +942,8 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   // workspace layout
   Arena& A = p->arena;
   size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / PIECE + 4) * 2 + sizeof(Flags) +
-                (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
-                256 * 24;
+                (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8 + 2 + 4) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
+                (n / PIECE + 4) * 5 + 256 * 32;
   int rc = A.reserve(need);
   if (rc) { delete s; return rc; }
   A.reset();
@@ -689,6 +954,8 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   s->len = A.take<uint32_t>(s->nblk); s->off = A.take<unsigned long long>(s->nblk);
   s->wsum = A.take<unsigned long long>(s->ngroups); s->woff = A.take<unsigned long long>(s->ngroups);
   s->d_map = A.take<uint8_t>(KX_MAX_LEAVES); s->d_const = A.take<uint32_t>(4);
+  s->pleaf = A.take<uint8_t>(n / PIECE + 4); s->pcum = A.take<int32_t>(n / PIECE + 4);
+  s->merge_piece = A.take<uint16_t>(s->nblk); s->ctot = A.take<uint32_t>(s->nblk);
   if (!p->have_events) {
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete s; return setErr(KX_E_HIP, "hipEventCreate failed"); }
     p->have_events = true;
@@ -707,7 +974,7 @@ static int readFlags(kx_shard* s) {
 
 static void fillFwd(kx_shard* s, kx_fwd_summary* out) {
   out->synced = s->have_end ? 1 : 0;
-  out->end_state = s->have_end ? s->hflags.end_state : 0;
+  out->end_state = s->have_end ? s->endId() : 0;
   out->head_len = s->head_len;
   out->fail_pos = s->hflags.fail_pos;
 }
@@ -717,7 +984,7 @@ int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
   kx_program* p = s->prog; Stage& S = *s->st;
   const uint32_t bt = p->cfg.block_threads;
   const bool timing = p->cfg.collect_timing;
-  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0; init.first_merged = 0xFFFFFFFFu;
+  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0 * S.nclasses; init.first_merged = 0xFFFFFFFFu;
   HIPCHECK(hipMemcpyAsync(s->flags, &init, sizeof(Flags), hipMemcpyHostToDevice, s->stream));
   if (s->n == 0) {  // nothing to scan: the state entering byte 0 is also the end state
     s->hflags = init; s->head_len = 0; s->have_end = s->is_first != 0;
@@ -726,8 +993,12 @@ int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
   }
   const uint32_t grid = (s->nseg + bt - 1) / bt;
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-  hipLaunchKernelGGL(k_sync, dim3(grid), dim3(bt), 0, s->stream, s->in, s->n, s->seg, s->nseg, s->is_first,
-                     s->seg_pos, s->seg_state, s->flags, S.T);
+  if (S.sync_lds_bytes)
+    hipLaunchKernelGGL((k_sync<true>), dim3(grid), dim3(bt), S.sync_lds_bytes, s->stream, s->in, s->n, s->seg, s->nseg,
+                       s->is_first, s->seg_pos, s->seg_state, s->flags, S.T);
+  else
+    hipLaunchKernelGGL((k_sync<false>), dim3(grid), dim3(bt), 0, s->stream, s->in, s->n, s->seg, s->nseg, s->is_first,
+                       s->seg_pos, s->seg_state, s->flags, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   hipLaunchKernelGGL(k_forward, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->nseg, s->seg_pos,
                      s->seg_state, s->chk, s->flags, S.T);
@@ -760,18 +1031,18 @@ int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out)
     if (incoming_state > S.nstates) return setErr(KX_E_ARG, "incoming state out of range");
     const bool timing = p->cfg.collect_timing;
     if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len, incoming_state,
-                       s->chk, s->flags, S.T);
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len,
+                       incoming_state * S.nclasses, s->chk, s->flags, S.T);
     if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
     HIPCHECK(hipGetLastError());
     int rc = readFlags(s);
     if (rc) return rc;
     if (timing) s->stats.kernel_ms[KX_K_HEAD] = evMs(p->ev[0], p->ev[1]);
   } else if (!s->is_first && s->n == 0) {
-    s->hflags.end_state = incoming_state;
+    s->hflags.end_state = incoming_state * S.nclasses;
   }
   s->have_end = true;
-  if (s->is_last && s->hflags.fail_pos == NOFAIL && S.h_fin_leaf[s->hflags.end_state] == KXP_NO_LEAF)
+  if (s->is_last && s->hflags.fail_pos == NOFAIL && S.h_fin_leaf[s->endId()] == KXP_NO_LEAF)
     s->hflags.fail_pos = s->n;  // end of input in a non-final state (C.hs NextI fallback → FailI)
   fillFwd(s, out);
   return 0;
@@ -781,7 +1052,7 @@ int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
   if (!s || !out) return setErr(KX_E_ARG, "null argument");
   kx_program* p = s->prog; Stage& S = *s->st;
   memset(out, 0, sizeof *out);
-  const uint32_t nle = S.h_nleaves[s->hflags.end_state];
+  const uint32_t nle = S.h_nleaves[s->endId()];
   out->nleaves = nle;
   if (s->n == 0) {  // identity map
     out->constant = 0;
@@ -794,10 +1065,12 @@ int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
   if (s->Lc <= 32)
     hipLaunchKernelGGL((k_backlen<32>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
-                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, S.T);
+                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->pleaf, s->pcum,
+                       s->merge_piece, s->ctot, S.T);
   else
     hipLaunchKernelGGL((k_backlen<256>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
-                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, S.T);
+                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->pleaf, s->pcum,
+                       s->merge_piece, s->ctot, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   if (!s->is_first) {  // the neighbouring rank needs our start leaf as a function of our end leaf
@@ -814,13 +1087,13 @@ int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
 int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
   if (!s || !out_len) return setErr(KX_E_ARG, "null argument");
   kx_program* p = s->prog; Stage& S = *s->st;
-  if (s->is_last) end_leaf = S.h_fin_leaf[s->hflags.end_state];
-  if (end_leaf >= S.h_nleaves[s->hflags.end_state]) return setErr(KX_E_ARG, "end leaf out of range");
+  if (s->is_last) end_leaf = S.h_fin_leaf[s->endId()];
+  if (end_leaf >= S.h_nleaves[s->endId()]) return setErr(KX_E_ARG, "end leaf out of range");
   if (s->n == 0) {
     s->init_shift = s->is_first ? S.h_init_len[end_leaf] : 0;
     s->out_len = s->init_shift;
     *out_len = s->out_len;
-    s->hflags.first_merged = end_leaf;  // remembered as the start leaf
+    s->init_leaf = end_leaf;  // no input: the start leaf is the end leaf
     return 0;
   }
   const uint32_t bt = p->cfg.block_threads;
@@ -830,6 +1103,8 @@ int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
                      s->bs_merged, s->bs_mstart, s->Lc, s->E, s->len, s->wsum);
   hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s->stream, s->ngroups, s->wsum, s->woff, s->flags);
   hipLaunchKernelGGL(k_scan_blocks, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, s->len, s->woff, s->off);
+  hipLaunchKernelGGL(k_fixtail, dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
+                     s->E, s->len, s->merge_piece, s->ctot, s->pleaf, s->pcum, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   uint8_t e0 = 0;
@@ -842,6 +1117,7 @@ int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
     uint8_t l0 = 0;
     HIPCHECK(hipMemcpy(&l0, s->bs_start + (size_t)e0, 1, hipMemcpyDeviceToHost));
     s->init_shift = S.h_init_len[l0];
+    s->init_leaf = l0;
   }
   s->out_len = s->hflags.total_len + s->init_shift;
   *out_len = s->out_len;
@@ -852,21 +1128,29 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   if (!s) return setErr(KX_E_ARG, "null argument");
   kx_program* p = s->prog; Stage& S = *s->st;
   if (cap < s->out_len || (s->out_len && !d_out)) return setErr(KX_E_CAPACITY, "output buffer too small");
+  if ((uintptr_t)d_out & 15) return setErr(KX_E_ARG, "output buffer must be 16-byte aligned");
   s->stats.out_bytes = s->out_len;
   if (s->n == 0) {
     if (s->init_shift) {
-      uint32_t leaf = s->hflags.first_merged;
+      uint32_t leaf = s->init_leaf;
       HIPCHECK(hipMemcpyAsync(d_out, S.h_pool.data() + S.h_init_off[leaf], s->init_shift, hipMemcpyHostToDevice, s->stream));
       HIPCHECK(hipStreamSynchronize(s->stream));
     }
     return 0;
   }
-  const uint32_t bt = p->cfg.block_threads;
-  const uint32_t grid = (s->nblk + bt - 1) / bt;
   const bool timing = p->cfg.collect_timing;
+  const uint64_t npieces = (s->n + PIECE - 1) / PIECE;
+  const uint64_t nwi = (npieces + 63) / 64;
+  const int W = p->emit_waves;
+  uint64_t want = (nwi + W - 1) / W;
+  const uint32_t grid = (uint32_t)(want < (uint64_t)p->ncu ? want : (uint64_t)p->ncu);
+  const size_t elds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)W * EMIT_WAVE_LDS;
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-  hipLaunchKernelGGL(k_emit, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk, s->E,
-                     s->len, s->off, s->bs_start, s->Lc, s->is_first, (uint8_t*)d_out, S.T);
+#define KX_LAUNCH_EMIT(WV)                                                                                       \
+  hipLaunchKernelGGL((k_emit<WV>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
+                     s->pleaf, s->pcum, s->ctot, s->off, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+  if (W == 16) KX_LAUNCH_EMIT(16); else if (W == 12) KX_LAUNCH_EMIT(12); else if (W == 8) KX_LAUNCH_EMIT(8); else KX_LAUNCH_EMIT(4);
+#undef KX_LAUNCH_EMIT
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize(s->stream));

@@ -61,13 +61,21 @@ constexpr int EMIT_JCAP = 384;            // k_emit: constant-copy jobs per wave
 constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JCAP * 8;
 
 // ------------------------------------------------------------------ device-side program view
-// States travel as *handles* h = state·C (the word offset of the state's row in `fwd`), so that a
-// transition is one add + one LDS read:  e = fwd[h + cls[byte]] ;  h' = e & 0xFFFF ;  back row = e >> 16.
+// The table image is copied verbatim into LDS (at LDS address 0 of the dynamic segment) and is
+// addressed by *byte offsets* that are stored pre-scaled inside the tables themselves, so that a
+// lookup is one add + one ds_read:
+//   state handle h   = byte offset of the state's row in fwd          (h = state·C·4)
+//   cls4[byte]       = class·4                                        (u16 table)
+//   e = fwd[h + cls4[b]] :  low 16 = next handle, high 16 = byte offset of the transition's back row
+//   back entry x = ent[row + leaf·4] : leaf'·4 (10 bits) | copy (1) | appended bytes (7) | pool offset (14)
+//     appended = 127 escapes to the wide side tables wlen/woff (global memory) for long constants.
 struct DevTables {
-  const uint32_t* packed;     // [fwd | back_lo | back_hi | pool | cls] — copied verbatim into LDS
+  const uint32_t* packed;     // [fwd | ent | pool | cls4] image
   uint32_t packed_words;
-  uint32_t off_blo, off_bhi, off_pool, off_cls;  // word offsets inside packed
+  uint32_t off_ent, off_pool, off_cls;  // byte offsets inside the image
   uint32_t nstates, nclasses, q0h, maxleaves, deadh, nullrow;
+  const uint32_t* wlen;       // [nent] appended byte count / pool offset per back entry (wide form)
+  const uint32_t* woff;
   const uint8_t* cls;         // global copy for kernels that do not stage the big image
   const uint8_t* nleaves;     // [nstates+1]  by state id
   const uint8_t* fin_leaf;    // [nstates+1]
@@ -78,15 +86,30 @@ struct DevTables {
 };
 
 struct Lds {
-  const uint32_t* fwd; const uint32_t* blo; const uint32_t* bhi; const uint8_t* pool; const uint8_t* cls;
+  const uint8_t* base; uint32_t cls, pool, ent;
+  __device__ __forceinline__ uint32_t w(uint32_t off) const { return *reinterpret_cast<const uint32_t*>(base + off); }
+  __device__ __forceinline__ uint32_t c4(uint32_t byte) const { return *reinterpret_cast<const uint16_t*>(base + cls + 2 * byte); }
+  __device__ __forceinline__ uint32_t next(uint32_t h, uint32_t byte) const { return w(h + c4(byte)); }
+  __device__ __forceinline__ uint8_t pb(uint32_t off) const { return base[pool + off]; }
 };
+#define E_LEAF4(e) ((e) & 0x3FFu)
+#define E_COPY(e) (((e) >> 10) & 1u)
+#define E_DLEN7(e) (((e) >> 11) & 0x7Fu)
+#define E_OFF14(e) ((e) >> 18)
+__device__ __forceinline__ uint32_t ent_dlen(uint32_t e, uint32_t addr, const Lds& L, const DevTables& T) {
+  uint32_t d = E_DLEN7(e);
+  if (__builtin_expect(d == 127u, 0)) d = T.wlen[(addr - L.ent) >> 2];
+  return d;
+}
+__device__ __forceinline__ uint32_t ent_off(uint32_t e, uint32_t addr, const Lds& L, const DevTables& T) {
+  return __builtin_expect(E_DLEN7(e) == 127u, 0) ? T.woff[(addr - L.ent) >> 2] : E_OFF14(e);
+}
 
 __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) {
   for (uint32_t i = threadIdx.x; i < T.packed_words; i += blockDim.x) smem[i] = T.packed[i];
   __syncthreads();
   Lds L;
-  L.fwd = smem; L.blo = smem + T.off_blo; L.bhi = smem + T.off_bhi;
-  L.pool = (const uint8_t*)(smem + T.off_pool); L.cls = (const uint8_t*)(smem + T.off_cls);
+  L.base = reinterpret_cast<const uint8_t*>(smem); L.cls = T.off_cls; L.pool = T.off_pool; L.ent = T.off_ent;
   return L;
 }
 
@@ -99,7 +122,6 @@ struct Flags {               // one per shard, device memory
   uint32_t pad;
 };
 
-__device__ __forceinline__ uint32_t byte_at(const uint32_t (&w)[16], int t) { return (w[t >> 2] >> ((t & 3) * 8)) & 0xFFu; }
 // Bit-field extract that the scheduler may not issue before `dep` exists.  The sweeps below are one
 // long dependency chain; without this the compiler unpacks all 64 bytes / 64 offsets of a piece up
 // front and holds them in ~128 VGPRs (measured: 181 VGPRs + scratch vs < 100).
@@ -165,7 +187,7 @@ __global__ void k_sync(const uint8_t* __restrict__ in, uint64_t n, uint64_t seg,
     ++pos;
   }
   const uint32_t st = sid < M ? 0xFFFFu : state_of[sid];
-  if (st < 0xFFF0u) { seg_pos[k] = (uint64_t)k * seg + cnt + (M ? 1 : 0); seg_state[k] = (uint16_t)(st * C); }
+  if (st < 0xFFF0u) { seg_pos[k] = (uint64_t)k * seg + cnt + (M ? 1 : 0); seg_state[k] = (uint16_t)(st * C * 4); }
   else { seg_pos[k] = UNSYNC; seg_state[k] = 0; atomicAdd(&flags->unsynced, 1u); }
 }
 
@@ -205,42 +227,65 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
   uint32_t h = seg_state[k];
   bool failed = false;
   while (pos < end && (pos & (PIECE - 1))) {
-    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { failed = true; break; }
     h = nh; ++pos;
   }
+  // 64 chained transitions over one piece held in registers
+  auto run_piece = [&](const uint32_t (&w)[16], uint32_t hh) {
+    uint32_t c[8], cn[8];
+    static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.c4(BYTE_AT_DEP(w, i, hh)); });
+    static_for<0, PIECE / 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 1 < PIECE / 8)
+        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.c4(BYTE_AT_DEP(w, 8 * (g + 1) + i, hh)); });
+      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; hh = L.w(hh + c[i]) & 0xFFFFu; });
+      if constexpr (g + 1 < PIECE / 8)
+        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = cn[i]; });
+    });
+    return hh;
+  };
+  auto locate = [&](uint32_t h0) {   // the run died inside the piece at `pos`: find the exact symbol
+    h = h0;
+    for (int t = 0; t < PIECE; ++t) {
+      uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
+      if (nh == dead) break;
+      h = nh; ++pos;
+    }
+    failed = true;
+  };
   while (!failed && pos + PIECE <= end) {
+    if ((pos & (8 * PIECE - 1)) == 0 && pos + 8 * PIECE <= end) {
+      // eight pieces per trip: their checkpoints leave as one aligned 16-byte store instead of eight
+      // scattered 2-byte stores (each of which dirties a whole 64-byte sector)
+      uint32_t cw[4];
+      bool died = false;
+      static_for<0, 8>([&](auto pc) {
+        constexpr int k8 = decltype(pc)::value;
+        if (!died) {
+          if constexpr (k8 & 1) cw[k8 >> 1] |= h << 16; else cw[k8 >> 1] = h;
+          uint32_t w[16];
+          load_piece(in, n, pos, w);
+          const uint32_t h0 = h;
+          h = run_piece(w, h);
+          if (h == dead) { locate(h0); died = true; }
+          else pos += PIECE;
+        }
+      });
+      if (!died) *reinterpret_cast<uint4*>(chk + ((pos >> 6) - 8)) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      continue;
+    }
     chk[pos >> 6] = (uint16_t)h;
     uint32_t w[16];
     load_piece(in, n, pos, w);
     const uint32_t h0 = h;
-    {
-      uint32_t c[8], cn[8];
-      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.cls[BYTE_AT_DEP(w, i, h)]; });
-      static_for<0, PIECE / 8>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if constexpr (g + 1 < PIECE / 8)
-          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.cls[BYTE_AT_DEP(w, 8 * (g + 1) + i, h)]; });
-        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; h = L.fwd[h + c[i]] & 0xFFFFu; });
-        if constexpr (g + 1 < PIECE / 8)
-          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = cn[i]; });
-      });
-    }
-    if (h == dead) {
-      h = h0;
-      for (int t = 0; t < PIECE; ++t) {
-        uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
-        if (nh == dead) break;
-        h = nh; ++pos;
-      }
-      failed = true;
-      break;
-    }
+    h = run_piece(w, h);
+    if (h == dead) { locate(h0); break; }
     pos += PIECE;
   }
   while (!failed && pos < end) {
     if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
-    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { failed = true; break; }
     h = nh; ++pos;
   }
@@ -260,7 +305,7 @@ __global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head
   const uint32_t dead = T.deadh;
   for (uint64_t pos = 0; pos < head_len; ++pos) {
     if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
-    uint32_t nh = L.fwd[h + L.cls[in[pos]]] & 0xFFFFu;
+    uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
     h = nh;
   }
@@ -284,7 +329,6 @@ __device__ __forceinline__ void launder(uint32_t (&a)[N]) {
 
 // back-row offsets are 16-bit: two steps share a VGPR (keeps the sweeps at 4+ waves per SIMD)
 constexpr int BOW = PIECE / 2;
-__device__ __forceinline__ uint32_t bo_get(const uint32_t (&bo)[BOW], int t) { return (t & 1) ? (bo[t >> 1] >> 16) : (bo[t >> 1] & 0xFFFFu); }
 __device__ __forceinline__ void bo_set(uint32_t (&bo)[BOW], int t, uint32_t v) {
   bo[t >> 1] = (t & 1) ? ((bo[t >> 1] & 0xFFFFu) | (v << 16)) : ((bo[t >> 1] & 0xFFFF0000u) | v);
 }
@@ -292,16 +336,16 @@ __device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t 
   // byte-class lookups do not depend on the state, so they are prefetched one group of 8 ahead of
   // the dependent fwd[] chain — and no further (all 64 at once would cost 64 VGPRs)
   uint32_t c[8], cn[8];
-  static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.cls[BYTE_AT_DEP(w, i, h)]; });
+  static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.c4(BYTE_AT_DEP(w, i, h)); });
   static_for<0, PIECE / 8>([&](auto gc) {
     constexpr int g = decltype(gc)::value;
     if constexpr (g + 1 < PIECE / 8)
-      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.cls[BYTE_AT_DEP(w, 8 * (g + 1) + i, h)]; });
+      static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.c4(BYTE_AT_DEP(w, 8 * (g + 1) + i, h)); });
     static_for<0, 4>([&](auto ic) {
       constexpr int i = 2 * decltype(ic)::value;
-      const uint32_t e0 = L.fwd[h + c[i]];
+      const uint32_t e0 = L.w(h + c[i]);
       h = e0 & 0xFFFFu;
-      const uint32_t e1 = L.fwd[h + c[i + 1]];
+      const uint32_t e1 = L.w(h + c[i + 1]);
       h = e1 & 0xFFFFu;
       bo[(8 * g + i) >> 1] = (e0 >> 16) | (e1 & 0xFFFF0000u);
     });
@@ -338,12 +382,12 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
-  const uint32_t qe = (bend == n ? flags->end_state : chk[bend >> 6]) / T.nclasses;
-  uint8_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];
+  const uint32_t qe = (bend == n ? flags->end_state : chk[bend >> 6]) / (T.nclasses * 4);
+  uint16_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];   // cl = leaf·4
   uint32_t nc, nact;
   uint32_t known = 0xFFFFFFFFu;
-  if (bend == n && is_last) { nc = 1; known = T.fin_leaf[qe]; cl[0] = (uint8_t)known; }
-  else { nc = T.nleaves[qe]; if (nc > MAXC) nc = MAXC; for (uint32_t j = 0; j < nc; ++j) cl[j] = (uint8_t)j; }
+  if (bend == n && is_last) { nc = 1; known = T.fin_leaf[qe]; cl[0] = (uint16_t)(known * 4); }
+  else { nc = T.nleaves[qe]; if (nc > MAXC) nc = MAXC; for (uint32_t j = 0; j < nc; ++j) cl[j] = (uint16_t)(j * 4); }
   for (uint32_t j = 0; j < nc; ++j) { clen[j] = 0; pre[j] = 0; }
   nact = nc;
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
@@ -357,14 +401,15 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     piece_forward(w, chk[pstart >> 6], L, bo);
     mask_tail(bo, plen, T.nullrow);
     const bool final_here = nact == 1;
-    if (final_here) pleaf[piece0 + p] = cl[0];
+    if (final_here) pleaf[piece0 + p] = (uint8_t)(cl[0] >> 2);
     for (uint32_t j = 0; j < nact; ++j) {
       uint32_t leaf = cl[j], sum = 0;
       static_for<0, PIECE>([&](auto ic) {
         constexpr int t = PIECE - 1 - decltype(ic)::value;
-        const uint32_t lo = L.blo[BO_GET_DEP(bo, t, leaf) + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; tie(leaf, sum);
+        const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+        const uint32_t e = L.w(a); sum += ent_dlen(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
       });
-      cl[j] = (uint8_t)leaf; clen[j] += sum;
+      cl[j] = (uint16_t)leaf; clen[j] += sum;
     }
     if (final_here) pcum[piece0 + p] = (int32_t)(clen[0] - pre[0]);
     else {
@@ -376,14 +421,14 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   const bool merged = nact == 1;
   const uint32_t tail = clen[0] - pre[0];
   if (known != 0xFFFFFFFFu) {
-    bs_start[(size_t)m * Lc + known] = cl[0]; bs_len[(size_t)m * Lc + known] = clen[0];
+    bs_start[(size_t)m * Lc + known] = (uint8_t)(cl[0] >> 2); bs_len[(size_t)m * Lc + known] = clen[0];
   } else if (merged) {  // after merging only candidate 0 kept accumulating
-    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[0]; bs_len[(size_t)m * Lc + j] = pre[j] + tail; }
+    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = (uint8_t)(cl[0] >> 2); bs_len[(size_t)m * Lc + j] = pre[j] + tail; }
   } else {
-    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = cl[j]; bs_len[(size_t)m * Lc + j] = clen[j]; }
+    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = (uint8_t)(cl[j] >> 2); bs_len[(size_t)m * Lc + j] = clen[j]; }
   }
   bs_merged[m] = merged ? 1 : 0;
-  bs_mstart[m] = cl[0];
+  bs_mstart[m] = (uint8_t)(cl[0] >> 2);
   merge_piece[m] = (uint16_t)(merged ? mp : 0);
   ctot[m] = merged ? tail : 0;
 }
@@ -504,7 +549,7 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   const uint32_t mp = merge_piece[m];
   if (mp >= npieces) return;
   const uint64_t piece0 = bstart >> 6;
-  uint32_t leaf = E[m], suffix = 0;
+  uint32_t leaf = (uint32_t)E[m] * 4, suffix = 0;
   const int32_t base = (int32_t)ctot[m] - (int32_t)len[m];
   for (uint32_t p = npieces; p-- > mp;) {
     const uint64_t pstart = bstart + (uint64_t)p * PIECE;
@@ -513,11 +558,12 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     load_piece(in, n, pstart, w);
     piece_forward(w, chk[pstart >> 6], L, bo);
     mask_tail(bo, plen, T.nullrow);
-    pleaf[piece0 + p] = (uint8_t)leaf;
+    pleaf[piece0 + p] = (uint8_t)(leaf >> 2);
     uint32_t sum = 0;
     static_for<0, PIECE>([&](auto ic) {
       constexpr int t = PIECE - 1 - decltype(ic)::value;
-      const uint32_t lo = L.blo[BO_GET_DEP(bo, t, leaf) + leaf]; sum += lo >> 9; leaf = lo & 0xFFu; tie(leaf, sum);
+      const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+      const uint32_t e = L.w(a); sum += ent_dlen(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
     });
     suffix += sum;
     pcum[piece0 + p] = base + (int32_t)suffix;
@@ -545,9 +591,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* stg = (uint8_t*)(smem + ((T.packed_words + 3) & ~3u)) + (size_t)wave * EMIT_WAVE_LDS;
   uint32_t* jobs = (uint32_t*)(stg + EMIT_STG + 16);
-  if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pool[T.init_off[init_leaf] + threadIdx.x];
+  if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pb(T.init_off[init_leaf] + threadIdx.x);
   if (is_first && blockIdx.x == 0 && init_shift > blockDim.x)
-    for (uint32_t i = blockDim.x + threadIdx.x; i < init_shift; i += blockDim.x) out[i] = L.pool[T.init_off[init_leaf] + i];
+    for (uint32_t i = blockDim.x + threadIdx.x; i < init_shift; i += blockDim.x) out[i] = L.pb(T.init_off[init_leaf] + i);
   const uint64_t nwi = (npieces_total + 63) / 64;
   for (uint64_t it = (uint64_t)blockIdx.x * WAVES + wave; it < nwi; it += (uint64_t)gridDim.x * WAVES) {
     const uint64_t piece = it * 64 + lane;
@@ -561,16 +607,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
     piece_forward(w, valid ? chk[piece] : T.deadh, L, bo);
     mask_tail(bo, plen, T.nullrow);
     {
-      uint32_t leaf = valid ? pleaf[piece] : 0u;
+      uint32_t leaf = valid ? (uint32_t)pleaf[piece] * 4 : 0u;
       static_for<0, PIECE>([&](auto ic) {
         constexpr int t = PIECE - 1 - decltype(ic)::value;
-        const uint32_t idx = BO_GET_DEP(bo, t, leaf) + leaf;
-        const uint32_t lo = L.blo[idx];
-        bo_set(bo, t, idx);
-        const uint32_t dl = lo >> 9;
+        const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+        const uint32_t e = L.w(a);
+        bo_set(bo, t, a);
+        const uint32_t dl = ent_dlen(e, a, L, T);
         olen += dl;
-        nj += dl > ((lo >> 8) & 1u) ? 1u : 0u;
-        leaf = lo & 0xFFu;
+        nj += dl > E_COPY(e) ? 1u : 0u;
+        leaf = E_LEAF4(e);
         tie(leaf, olen); tie(leaf, nj);
       });
     }
@@ -598,11 +644,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
           uint64_t o = ostart;
           static_for<0, PIECE>([&](auto ic) {
             constexpr int t = decltype(ic)::value;
-            const uint32_t idx = BO_GET_DEP(bo, t, (uint32_t)o);
-            const uint32_t lo = L.blo[idx], hi = L.bhi[idx];
-            const uint32_t cp = (lo >> 8) & 1u, cl = (lo >> 9) - cp;
-            if (cp) out[o++] = (uint8_t)BYTE_AT_DEP(w, t, idx);
-            for (uint32_t i = 0; i < cl; ++i) out[o++] = L.pool[hi + i];
+            const uint32_t a = BO_GET_DEP(bo, t, (uint32_t)o);
+            const uint32_t e = L.w(a);
+            const uint32_t cp = E_COPY(e), cl = ent_dlen(e, a, L, T) - cp, src = ent_off(e, a, L, T);
+            if (cp) out[o++] = (uint8_t)BYTE_AT_DEP(w, t, a);
+            for (uint32_t i = 0; i < cl; ++i) out[o++] = L.pb(src + i);
           });
         }
         first += 1;
@@ -615,14 +661,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       if (active) {
         uint32_t o = (uint32_t)(ostart - abase);
         uint32_t ji = (pj - nj) - pj_before;
-        static_for<0, PIECE>([&](auto ic) {
-          constexpr int t = decltype(ic)::value;
-          const uint32_t idx = BO_GET_DEP(bo, t, o);
-          const uint32_t lo = L.blo[idx];
-          const uint32_t cp = (lo >> 8) & 1u, dl = lo >> 9;
-          if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, idx);
-          if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = L.bhi[idx]; ++ji; }
-          o += dl;
+        // table words of 8 steps are fetched together (they are independent of each other); the offset
+        // chain then runs on registers
+        static_for<0, PIECE / 8>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          uint32_t a8[8], e8[8];
+          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; a8[i] = BO_GET_DEP(bo, 8 * g + i, o); e8[i] = L.w(a8[i]); });
+          static_for<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int t = 8 * g + i;
+            const uint32_t e = e8[i];
+            const uint32_t cp = E_COPY(e), dl = ent_dlen(e, a8[i], L, T);
+            if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, e);
+            if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = ent_off(e, a8[i], L, T); ++ji; }
+            o += dl;
+          });
         });
       }
       wave_lds_fence();
@@ -631,7 +684,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       for (uint32_t j = lane; j < njobs; j += 64) {
         const uint32_t a = jobs[2 * j], src = jobs[2 * j + 1];
         const uint32_t d = a & 0xFFFFu, l = a >> 16;
-        for (uint32_t i = 0; i < l; ++i) stg[d + i] = L.pool[src + i];
+        uint32_t i = 0;
+        for (; i + 4 <= l; i += 4) {
+          const uint8_t b0 = L.pb(src + i), b1 = L.pb(src + i + 1), b2 = L.pb(src + i + 2), b3 = L.pb(src + i + 3);
+          stg[d + i] = b0; stg[d + i + 1] = b1; stg[d + i + 2] = b2; stg[d + i + 3] = b3;
+        }
+        for (; i < l; ++i) stg[d + i] = L.pb(src + i);
       }
       wave_lds_fence();
       // flush [gs, ge): partial head and tail windows bytewise, everything between as aligned 16 B
@@ -709,7 +767,7 @@ struct kx_shard {
   unsigned long long *off, *wsum, *woff;
   // control state mirrored on the host
   Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0, init_leaf = 0;
-  uint32_t endId() const { return hflags.end_state / st->nclasses; }
+  uint32_t endId() const { return hflags.end_state / (st->nclasses * 4); }
   kx_stats stats{};
 };
 
@@ -742,55 +800,62 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t* sync_next = (const uint32_t*)c; c += (size_t)nsync * C * 4;
   const uint32_t* sync_state = (const uint32_t*)c; c += (size_t)nsync * 4;
   if (c > end) return setErr(KX_E_BLOB, "truncated stage body");
-  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C > 0xFFF0)
+  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C * 4 > 0xFFF0)
     return setErr(KX_E_BLOB, "program outside engine limits (states x classes / leaves)");
 
   S.nstates = nstates; S.nclasses = C; S.q0 = q0; S.maxleaves = Lm;
-  // ragged back rows: row b keeps entries up to its last live leaf
-  std::vector<uint32_t> rowoff(nback), blo, bhi;
+  // ragged back rows: row b keeps entries up to its last live leaf.  Compact entry (see DevTables);
+  // entries that do not fit (≥127 appended bytes, pool offset ≥ 16 KiB) escape to the wide side tables.
+  std::vector<uint32_t> rowoff(nback), ent, wlen, woff;
+  auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
+    const bool wide = dlen >= 127 || poff >= (1u << 14);
+    ent.push_back((parent * 4) | (copy << 10) | ((wide ? 127u : dlen) << 11) | ((wide ? 0u : poff) << 18));
+    wlen.push_back(dlen); woff.push_back(poff);
+  };
   for (uint32_t b = 0; b < nback; ++b) {
     uint32_t rl = 1;
     for (uint32_t j = 0; j < Lm; ++j) if (back[(size_t)b * Lm + j] != KXP_DEAD_LEAF) rl = j + 1;
-    rowoff[b] = (uint32_t)blo.size();
+    rowoff[b] = (uint32_t)ent.size();
     for (uint32_t j = 0; j < rl; ++j) {
       uint32_t e = back[(size_t)b * Lm + j];
-      if (e == KXP_DEAD_LEAF) { blo.push_back(0); bhi.push_back(0); continue; }
+      if (e == KXP_DEAD_LEAF) { pushEnt(0, 0, 0, 0); continue; }
       uint32_t parent = e & 0xFF, copy = (e >> 8) & 1, pc = e >> 9;
       uint32_t clen = pcoff[pc + 1] - pcoff[pc];
       if (clen + copy >= (1u << 23)) return setErr(KX_E_BLOB, "path constant too long");
-      blo.push_back(parent | (copy << 8) | ((clen + copy) << 9));
-      bhi.push_back(pcoff[pc]);
+      pushEnt(parent, copy, clen + copy, pcoff[pc]);
     }
   }
   // identity row (parent = leaf, nothing appended): steps past the end of a partial piece point here;
-  // it also pads the table so that a probe on a dead path stays inside it
-  const uint32_t nullrow = (uint32_t)blo.size();
-  for (uint32_t j = 0; j < Lm; ++j) { blo.push_back(j); bhi.push_back(0); }
-  for (uint32_t j = 0; j < Lm; ++j) { blo.push_back(0); bhi.push_back(0); }
-  if (blo.size() >= 65536) return setErr(KX_E_BLOB, "backward table exceeds 65535 entries");
-  const uint32_t deadh = nstates * C;                 // handle of the absorbing "no transition" state
+  // a second, all-zero row pads the table so that a probe on a dead path stays inside it
+  const uint32_t nullrow_idx = (uint32_t)ent.size();
+  for (uint32_t j = 0; j < Lm; ++j) pushEnt(j, 0, 0, 0);
+  for (uint32_t j = 0; j < Lm; ++j) pushEnt(0, 0, 0, 0);
+  const uint32_t fwd_bytes = (nstates + 1) * C * 4;
+  const uint32_t off_ent = fwd_bytes;
+  if ((size_t)off_ent + ent.size() * 4 > 65532)
+    return setErr(KX_E_BLOB, "program tables exceed the engine's 16-bit LDS addressing (states x classes + path table > 64 KiB)");
+  const uint32_t deadh = nstates * C * 4;              // handle of the absorbing "no transition" state
   std::vector<uint32_t> fwd((size_t)(nstates + 1) * C);
   for (uint32_t q = 0; q < nstates; ++q)
     for (uint32_t k = 0; k < C; ++k) {
       uint16_t d = delta[(size_t)q * C + k];
-      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? deadh : ((uint32_t)d * C | (rowoff[pback[(size_t)q * C + k]] << 16));
+      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? deadh
+                               : ((uint32_t)d * C * 4 | ((off_ent + rowoff[pback[(size_t)q * C + k]] * 4) << 16));
     }
   for (uint32_t k = 0; k < C; ++k) fwd[(size_t)nstates * C + k] = deadh;
 
-  // packed LDS image: fwd | back_lo | back_hi | pool | cls
+  // LDS image: fwd | ent | pool | cls4
   std::vector<uint32_t> packed(fwd);
-  const uint32_t off_blo = (uint32_t)packed.size();
-  packed.insert(packed.end(), blo.begin(), blo.end());
-  const uint32_t off_bhi = (uint32_t)packed.size();
-  packed.insert(packed.end(), bhi.begin(), bhi.end());
-  const uint32_t off_pool = (uint32_t)packed.size();
+  packed.insert(packed.end(), ent.begin(), ent.end());
+  const uint32_t off_pool = (uint32_t)packed.size() * 4;
   packed.resize(packed.size() + pad4(pcpl + 4) / 4, 0);
-  memcpy(&packed[off_pool], pcpool, pcpl);
-  const uint32_t off_cls = (uint32_t)packed.size();
-  packed.resize(packed.size() + 64);
-  memcpy(&packed[off_cls], cls, 256);
+  memcpy((char*)packed.data() + off_pool, pcpool, pcpl);
+  const uint32_t off_cls = (uint32_t)packed.size() * 4;
+  packed.resize(packed.size() + 128);
+  for (int b = 0; b < 256; ++b) ((uint16_t*)((char*)packed.data() + off_cls))[b] = (uint16_t)(cls[b] * 4);
   S.lds_bytes = packed.size() * 4;
   if (S.lds_bytes > 150 * 1024) return setErr(KX_E_BLOB, "program tables exceed the LDS budget (150 KiB)");
+  const uint32_t nullrow = off_ent + nullrow_idx * 4;
 
   S.h_nleaves.assign(nleaves, nleaves + nstates); S.h_nleaves.push_back(1);
   S.h_fin_leaf.assign(fin_leaf, fin_leaf + nstates); S.h_fin_leaf.push_back(KXP_NO_LEAF);
@@ -824,7 +889,8 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t o_packed = 0, o_cls = o_packed + al(packed.size() * 4), o_nl = o_cls + 256, o_fl = o_nl + al(nstates + 1),
          o_sn = o_fl + al(nstates + 1), o_io = o_sn + al(sync_bytes),
-         o_il = o_io + al(Lm * 4), total = o_il + al(Lm * 4);
+         o_il = o_io + al(Lm * 4), o_wl = o_il + al(Lm * 4), o_wo = o_wl + al(wlen.size() * 4),
+         total = o_wo + al(woff.size() * 4);
   std::vector<uint8_t> img(total, 0);
   memcpy(&img[o_packed], packed.data(), packed.size() * 4);
   memcpy(&img[o_cls], cls, 256);
@@ -833,13 +899,16 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   memcpy(&img[o_sn], sync16.data(), sync_bytes);
   memcpy(&img[o_io], S.h_init_off.data(), Lm * 4);
   memcpy(&img[o_il], S.h_init_len.data(), Lm * 4);
+  memcpy(&img[o_wl], wlen.data(), wlen.size() * 4);
+  memcpy(&img[o_wo], woff.data(), woff.size() * 4);
   HIPCHECK(hipMalloc(&S.d_all, total));
   HIPCHECK(hipMemcpy(S.d_all, img.data(), total, hipMemcpyHostToDevice));
   char* d = (char*)S.d_all;
   DevTables& T = S.T;
   T.packed = (const uint32_t*)(d + o_packed); T.packed_words = (uint32_t)packed.size();
-  T.off_blo = off_blo; T.off_bhi = off_bhi; T.off_pool = off_pool; T.off_cls = off_cls;
-T.nstates = nstates; T.nclasses = C; T.q0h = q0 * C; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
+  T.off_ent = off_ent; T.off_pool = off_pool; T.off_cls = off_cls;
+  T.wlen = (const uint32_t*)(d + o_wl); T.woff = (const uint32_t*)(d + o_wo);
+T.nstates = nstates; T.nclasses = C; T.q0h = q0 * C * 4; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
   T.cls = (const uint8_t*)(d + o_cls); T.nleaves = (const uint8_t*)(d + o_nl); T.fin_leaf = (const uint8_t*)(d + o_fl);
   T.sync16 = (const uint16_t*)(d + o_sn); T.nsync = nsync; T.sync_multi = nmulti; T.sync_words = (uint32_t)(sync_bytes / 4);
   T.init_off = (const uint32_t*)(d + o_io); T.init_len = (const uint32_t*)(d + o_il);
@@ -984,7 +1053,7 @@ int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
   kx_program* p = s->prog; Stage& S = *s->st;
   const uint32_t bt = p->cfg.block_threads;
   const bool timing = p->cfg.collect_timing;
-  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0 * S.nclasses; init.first_merged = 0xFFFFFFFFu;
+  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0 * S.nclasses * 4; init.first_merged = 0xFFFFFFFFu;
   HIPCHECK(hipMemcpyAsync(s->flags, &init, sizeof(Flags), hipMemcpyHostToDevice, s->stream));
   if (s->n == 0) {  // nothing to scan: the state entering byte 0 is also the end state
     s->hflags = init; s->head_len = 0; s->have_end = s->is_first != 0;
@@ -1032,14 +1101,14 @@ int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out)
     const bool timing = p->cfg.collect_timing;
     if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
     hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len,
-                       incoming_state * S.nclasses, s->chk, s->flags, S.T);
+                       incoming_state * S.nclasses * 4, s->chk, s->flags, S.T);
     if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
     HIPCHECK(hipGetLastError());
     int rc = readFlags(s);
     if (rc) return rc;
     if (timing) s->stats.kernel_ms[KX_K_HEAD] = evMs(p->ev[0], p->ev[1]);
   } else if (!s->is_first && s->n == 0) {
-    s->hflags.end_state = incoming_state * S.nclasses;
+    s->hflags.end_state = incoming_state * S.nclasses * 4;
   }
   s->have_end = true;
   if (s->is_last && s->hflags.fail_pos == NOFAIL && S.h_fin_leaf[s->endId()] == KXP_NO_LEAF)

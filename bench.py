@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0, help="input GiB per GPU")
     ap.add_argument("--program", default="apache_log")
     ap.add_argument("--segment", type=int, default=0)
+    ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
     assert world == a.gpus, "launch with torch.distributed.run for --gpus > 1"
 
     blob = compile_file(a.program)
-    prog = Program(blob, segment_bytes=a.segment, collect_timing=True)
+    prog = Program(blob, segment_bytes=a.segment, block_threads=a.block_threads, collect_timing=True)
     shape = workloads.PROGRAM_INPUT[a.program]
     per_gpu = int(a.gib * (1 << 30))
     base = workloads.generate(shape, min(32 << 20, per_gpu), seed=0x4B4C4558)
@@ -163,7 +164,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s.kex, %.2f GiB synthetic %s per GPU (seeded 32 MiB chunk replicated, "
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
-                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or 4096,
+                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or "auto (4-16 KiB by input size)",
                        "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,

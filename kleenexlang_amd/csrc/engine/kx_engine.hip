@@ -96,13 +96,18 @@ struct Lds {
 #define E_COPY(e) (((e) >> 10) & 1u)
 #define E_DLEN7(e) (((e) >> 11) & 0x7Fu)
 #define E_OFF14(e) ((e) >> 18)
+// WIDE = the program has back entries in the escaped wide form (long constants); programs without
+// them (all five workloads) run kernel instances in which the escape test does not exist at all.
+template <bool WIDE>
 __device__ __forceinline__ uint32_t ent_dlen(uint32_t e, uint32_t addr, const Lds& L, const DevTables& T) {
   uint32_t d = E_DLEN7(e);
-  if (__builtin_expect(d == 127u, 0)) d = T.wlen[(addr - L.ent) >> 2];
+  if (WIDE) { if (__builtin_expect(d == 127u, 0)) d = T.wlen[(addr - L.ent) >> 2]; }
   return d;
 }
+template <bool WIDE>
 __device__ __forceinline__ uint32_t ent_off(uint32_t e, uint32_t addr, const Lds& L, const DevTables& T) {
-  return __builtin_expect(E_DLEN7(e) == 127u, 0) ? T.woff[(addr - L.ent) >> 2] : E_OFF14(e);
+  if (WIDE) { if (__builtin_expect(E_DLEN7(e) == 127u, 0)) return T.woff[(addr - L.ent) >> 2]; }
+  return E_OFF14(e);
 }
 
 __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) {
@@ -112,6 +117,9 @@ __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) 
   L.base = reinterpret_cast<const uint8_t*>(smem); L.cls = T.off_cls; L.pool = T.off_pool; L.ent = T.off_ent;
   return L;
 }
+
+// per-piece result of the backward length pass: end leaf and running output length (see k_backlen)
+struct __attribute__((aligned(8))) PieceRec { int32_t cum; uint32_t leaf; };
 
 struct Flags {               // one per shard, device memory
   unsigned long long fail_pos;
@@ -369,15 +377,17 @@ __device__ __forceinline__ void mask_tail(uint32_t (&bo)[BOW], int plen, uint32_
 // collapse to one as soon as they agree; from there on the per-piece end leaf and the running
 // output length are final and are written out for k_emit (pleaf/pcum).  Pieces above the merge
 // point (the block's tail) are finished by k_fixtail once the block's end leaf is known.
-template <int MAXC>
+template <int MAXC, bool WIDE>
 __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const Flags* flags, int is_last,
                           uint8_t* __restrict__ bs_start, uint32_t* __restrict__ bs_len, uint8_t* __restrict__ bs_merged,
-                          uint8_t* __restrict__ bs_mstart, uint32_t Lc, uint8_t* __restrict__ pleaf,
-                          int32_t* __restrict__ pcum, uint16_t* __restrict__ merge_piece, uint32_t* __restrict__ ctot,
-                          DevTables T) {
+                          uint8_t* __restrict__ bs_mstart, uint32_t Lc, PieceRec* __restrict__ prec,
+                          uint16_t* __restrict__ merge_piece, uint32_t* __restrict__ ctot, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
+  // per-lane staging behind the table image: 8 piece records (64 B) and 8 checkpoints (16 B), so that
+  // both move as whole aligned 64/16-byte lines instead of scattered 1-4 byte accesses
+  uint4* lrec = reinterpret_cast<uint4*>(smem + ((T.packed_words + 3) & ~3u)) + (size_t)threadIdx.x * 5;
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
@@ -392,27 +402,43 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   nact = nc;
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
   const uint64_t piece0 = bstart >> 6;
+  const bool batch = (blk & (8 * PIECE - 1)) == 0;   // blocks start on an 8-piece boundary
   uint32_t mp = nact == 1 ? npieces : 0;   // pieces [mp, npieces) form the unresolved tail
   for (uint32_t p = npieces; p-- > 0;) {
     const uint64_t pstart = bstart + (uint64_t)p * PIECE;
     const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
     uint32_t w[16], bo[BOW];
     load_piece(in, n, pstart, w);
-    piece_forward(w, chk[pstart >> 6], L, bo);
+    // checkpoints arrive 8 at a time (k_forward stores them that way); the piece index is 8-aligned
+    // with the block, so group (p | 7) is fetched when the sweep first enters it
+    uint32_t hstart;
+    if (batch) {
+      if ((p & 7) == 7 || p == npieces - 1) lrec[4] = *reinterpret_cast<const uint4*>(chk + ((piece0 + p) & ~7ull));
+      hstart = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
+    } else hstart = chk[piece0 + p];
+    piece_forward(w, hstart, L, bo);
     mask_tail(bo, plen, T.nullrow);
     const bool final_here = nact == 1;
-    if (final_here) pleaf[piece0 + p] = (uint8_t)(cl[0] >> 2);
+    const uint32_t leaf_end = cl[0] >> 2;
     for (uint32_t j = 0; j < nact; ++j) {
       uint32_t leaf = cl[j], sum = 0;
       static_for<0, PIECE>([&](auto ic) {
         constexpr int t = PIECE - 1 - decltype(ic)::value;
         const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
-        const uint32_t e = L.w(a); sum += ent_dlen(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
+        const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
       });
       cl[j] = (uint16_t)leaf; clen[j] += sum;
     }
-    if (final_here) pcum[piece0 + p] = (int32_t)(clen[0] - pre[0]);
-    else {
+    if (final_here) {
+      const PieceRec rec{(int32_t)(clen[0] - pre[0]), leaf_end};
+      if (batch) {
+        reinterpret_cast<PieceRec*>(lrec)[p & 7] = rec;
+        if ((p & 7) == 0) {   // records p..p+7 are complete (or belong to the unresolved tail: k_fixtail rewrites those)
+          uint4* dst = reinterpret_cast<uint4*>(prec + piece0 + p);
+          dst[0] = lrec[0]; dst[1] = lrec[1]; dst[2] = lrec[2]; dst[3] = lrec[3];
+        }
+      } else prec[piece0 + p] = rec;
+    } else {
       bool same = true;
       for (uint32_t j = 1; j < nact; ++j) same = same && cl[j] == cl[0];
       if (same) { for (uint32_t j = 0; j < nc; ++j) pre[j] = clen[j]; nact = 1; mp = p; }
@@ -534,11 +560,11 @@ __global__ void k_shard_map(uint32_t nblk, uint32_t nleaves_end, const uint8_t* 
 // With the block's end leaf E known, walk the unresolved tail pieces [merge_piece, npieces) again
 // and write their end leaf and offset in the convention of k_backlen:
 //   output offset of piece p inside its block = ctot[m] - pcum[p].
+template <bool WIDE>
 __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
                           const uint32_t* __restrict__ len, const uint16_t* __restrict__ merge_piece,
-                          const uint32_t* __restrict__ ctot, uint8_t* __restrict__ pleaf, int32_t* __restrict__ pcum,
-                          DevTables T) {
+                          const uint32_t* __restrict__ ctot, PieceRec* __restrict__ prec, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,15 +584,15 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     load_piece(in, n, pstart, w);
     piece_forward(w, chk[pstart >> 6], L, bo);
     mask_tail(bo, plen, T.nullrow);
-    pleaf[piece0 + p] = (uint8_t)(leaf >> 2);
+    const uint32_t leaf_end = leaf >> 2;
     uint32_t sum = 0;
     static_for<0, PIECE>([&](auto ic) {
       constexpr int t = PIECE - 1 - decltype(ic)::value;
       const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
-      const uint32_t e = L.w(a); sum += ent_dlen(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
+      const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
     });
     suffix += sum;
-    pcum[piece0 + p] = base + (int32_t)suffix;
+    prec[piece0 + p] = PieceRec{base + (int32_t)suffix, leaf_end};
   }
 }
 
@@ -579,10 +605,10 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
 // flushes it with aligned 16-byte stores.  Persistent workgroups: tables are staged once per CU.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
-template <int WAVES>
+template <int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
-                                                     const uint8_t* __restrict__ pleaf, const int32_t* __restrict__ pcum,
+                                                     const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
                                                      const unsigned long long* __restrict__ off, uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
@@ -606,14 +632,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
     load_piece(in, n, valid ? pstart : n, w);
     piece_forward(w, valid ? chk[piece] : T.deadh, L, bo);
     mask_tail(bo, plen, T.nullrow);
+    const PieceRec rec = valid ? prec[piece] : PieceRec{0, 0};
     {
-      uint32_t leaf = valid ? (uint32_t)pleaf[piece] * 4 : 0u;
+      uint32_t leaf = rec.leaf * 4;
       static_for<0, PIECE>([&](auto ic) {
         constexpr int t = PIECE - 1 - decltype(ic)::value;
         const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
         const uint32_t e = L.w(a);
         bo_set(bo, t, a);
-        const uint32_t dl = ent_dlen(e, a, L, T);
+        const uint32_t dl = ent_dlen<WIDE>(e, a, L, T);
         olen += dl;
         nj += dl > E_COPY(e) ? 1u : 0u;
         leaf = E_LEAF4(e);
@@ -622,7 +649,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
     }
     if (valid) {
       const uint64_t m = pstart / blk;
-      ostart = (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - pcum[piece]);
+      ostart = (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - rec.cum);
     }
     // inclusive prefix of the job counts over the wave
     uint32_t pj = nj;
@@ -646,7 +673,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
             constexpr int t = decltype(ic)::value;
             const uint32_t a = BO_GET_DEP(bo, t, (uint32_t)o);
             const uint32_t e = L.w(a);
-            const uint32_t cp = E_COPY(e), cl = ent_dlen(e, a, L, T) - cp, src = ent_off(e, a, L, T);
+            const uint32_t cp = E_COPY(e), cl = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
             if (cp) out[o++] = (uint8_t)BYTE_AT_DEP(w, t, a);
             for (uint32_t i = 0; i < cl; ++i) out[o++] = L.pb(src + i);
           });
@@ -671,9 +698,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
             constexpr int i = decltype(ic)::value;
             constexpr int t = 8 * g + i;
             const uint32_t e = e8[i];
-            const uint32_t cp = E_COPY(e), dl = ent_dlen(e, a8[i], L, T);
+            const uint32_t cp = E_COPY(e), dl = ent_dlen<WIDE>(e, a8[i], L, T);
             if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, e);
-            if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = ent_off(e, a8[i], L, T); ++ji; }
+            if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = ent_off<WIDE>(e, a8[i], L, T); ++ji; }
             o += dl;
           });
         });
@@ -719,6 +746,7 @@ struct Stage {
   DevTables T{};
   size_t lds_bytes = 0;                                // packed table image
   size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
+  bool wide = false;                                   // some back entry needs the escaped wide form
 };
 
 struct Arena {  // grow-only device workspace, reused across runs
@@ -745,7 +773,7 @@ struct Arena {  // grow-only device workspace, reused across runs
 
 struct kx_program {
   std::vector<Stage> stages;
-  kx_config cfg{4096, 256, 0};
+  kx_config cfg{0, 512, 0};
   Arena arena;                     // shard workspace
   void* stagebuf[2] = {nullptr, nullptr};   // ping-pong buffers between pipeline stages
   size_t stagecap[2] = {0, 0};
@@ -762,8 +790,8 @@ struct kx_shard {
   uint64_t seg; uint32_t nseg, nblk, Lc, ngroups;
   // workspace
   uint64_t* seg_pos; uint16_t* seg_state; uint16_t* chk; Flags* flags;
-  uint8_t *bs_start, *bs_merged, *bs_mstart, *E, *d_map, *pleaf; uint32_t *bs_len, *len, *d_const, *ctot;
-  int32_t* pcum; uint16_t* merge_piece;
+  uint8_t *bs_start, *bs_merged, *bs_mstart, *E, *d_map; uint32_t *bs_len, *len, *d_const, *ctot;
+  PieceRec* prec; uint16_t* merge_piece;
   unsigned long long *off, *wsum, *woff;
   // control state mirrored on the host
   Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0, init_leaf = 0;
@@ -809,6 +837,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   std::vector<uint32_t> rowoff(nback), ent, wlen, woff;
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
     const bool wide = dlen >= 127 || poff >= (1u << 14);
+    if (wide) S.wide = true;
     ent.push_back((parent * 4) | (copy << 10) | ((wide ? 127u : dlen) << 11) | ((wide ? 0u : poff) << 18));
     wlen.push_back(dlen); woff.push_back(poff);
   };
@@ -959,13 +988,19 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   if (tab + 4 * (size_t)EMIT_WAVE_LDS > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
   int rc = setLds((const void*)k_forward, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_head, lds); if (rc) { kx_free(p); return rc; }
-  rc = setLds((const void*)k_backlen<32>, lds); if (rc) { kx_free(p); return rc; }
-  rc = setLds((const void*)k_backlen<256>, lds); if (rc) { kx_free(p); return rc; }
-  rc = setLds((const void*)k_fixtail, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<32, false>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<32, true>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<256, false>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_backlen<256, true>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_fixtail<false>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_fixtail<true>, lds); if (rc) { kx_free(p); return rc; }
   if (slds) { rc = setLds((const void*)k_sync<true>, slds); if (rc) { kx_free(p); return rc; } }
   const size_t elds = tab + (size_t)p->emit_waves * EMIT_WAVE_LDS;
-  rc = p->emit_waves == 16 ? setLds((const void*)k_emit<16>, elds) : p->emit_waves == 12 ? setLds((const void*)k_emit<12>, elds)
-       : p->emit_waves == 8 ? setLds((const void*)k_emit<8>, elds) : setLds((const void*)k_emit<4>, elds);
+  bool anywide = false;
+  for (auto& s : p->stages) anywide = anywide || s.wide;
+#define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, false>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, true>, elds) : 0))
+  rc = p->emit_waves == 16 ? KX_EMIT_ATTR(16) : p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
+#undef KX_EMIT_ATTR
   if (rc) { kx_free(p); return rc; }
   *prog = p;
   return 0;
@@ -983,8 +1018,7 @@ void kx_free(kx_program* p) {
 int kx_set_config(kx_program* p, const kx_config* cfg) {
   if (!p || !cfg) return setErr(KX_E_ARG, "null argument");
   kx_config c = *cfg;
-  if (c.segment_bytes == 0) c.segment_bytes = 4096;
-  if (c.block_threads == 0) c.block_threads = 256;
+  if (c.block_threads == 0) c.block_threads = 512;
   if (c.segment_bytes % PIECE || c.segment_bytes > 65535u * PIECE || c.block_threads % 64 || c.block_threads > 1024 ||
       (c.block_threads & (c.block_threads - 1)))
     return setErr(KX_E_ARG, "segment_bytes: multiple of 64 (≤ 4 MiB); block_threads: power of two in [64, 1024]");
@@ -1003,6 +1037,7 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   s->prog = p; s->st = &p->stages[stage]; s->stage = stage;
   s->in = (const uint8_t*)d_in; s->n = n; s->is_first = is_first; s->is_last = is_last; s->stream = (hipStream_t)stream;
   s->seg = p->cfg.segment_bytes;
+  if (s->seg == 0) s->seg = (n >> 14) >= (512u << 10) ? 16384 : (n >> 13) >= (512u << 10) ? 8192 : 4096;   // keep ≥ 512 Ki lanes
   uint64_t ns = n ? (n + s->seg - 1) / s->seg : 1;
   if (ns > 0x7FFFFFF0ull) { delete s; return setErr(KX_E_ARG, "input too large for the configured segment size"); }
   s->nseg = (uint32_t)ns; s->nblk = s->nseg; s->Lc = s->st->maxleaves;
@@ -1010,20 +1045,20 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   s->ngroups = (s->nblk + bt - 1) / bt;
   // workspace layout
   Arena& A = p->arena;
-  size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / PIECE + 4) * 2 + sizeof(Flags) +
+  size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / PIECE + 16) * 2 + sizeof(Flags) +
                 (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8 + 2 + 4) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
-                (n / PIECE + 4) * 5 + 256 * 32;
+                (n / PIECE + 16) * 8 + 256 * 32;
   int rc = A.reserve(need);
   if (rc) { delete s; return rc; }
   A.reset();
   s->seg_pos = A.take<uint64_t>(s->nseg); s->seg_state = A.take<uint16_t>(s->nseg);
-  s->chk = A.take<uint16_t>(n / PIECE + 4); s->flags = A.take<Flags>(1);
+  s->chk = A.take<uint16_t>(n / PIECE + 16); s->flags = A.take<Flags>(1);
   s->bs_start = A.take<uint8_t>((size_t)s->nblk * s->Lc); s->bs_len = A.take<uint32_t>((size_t)s->nblk * s->Lc);
   s->bs_merged = A.take<uint8_t>(s->nblk); s->bs_mstart = A.take<uint8_t>(s->nblk); s->E = A.take<uint8_t>(s->nblk);
   s->len = A.take<uint32_t>(s->nblk); s->off = A.take<unsigned long long>(s->nblk);
   s->wsum = A.take<unsigned long long>(s->ngroups); s->woff = A.take<unsigned long long>(s->ngroups);
   s->d_map = A.take<uint8_t>(KX_MAX_LEAVES); s->d_const = A.take<uint32_t>(4);
-  s->pleaf = A.take<uint8_t>(n / PIECE + 4); s->pcum = A.take<int32_t>(n / PIECE + 4);
+  s->prec = A.take<PieceRec>(n / PIECE + 16);
   s->merge_piece = A.take<uint16_t>(s->nblk); s->ctot = A.take<uint32_t>(s->nblk);
   if (!p->have_events) {
     for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete s; return setErr(KX_E_HIP, "hipEventCreate failed"); }
@@ -1132,14 +1167,14 @@ int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
   const uint32_t grid = (s->nblk + bt - 1) / bt;
   const bool timing = p->cfg.collect_timing;
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-  if (s->Lc <= 32)
-    hipLaunchKernelGGL((k_backlen<32>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
-                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->pleaf, s->pcum,
-                       s->merge_piece, s->ctot, S.T);
-  else
-    hipLaunchKernelGGL((k_backlen<256>), dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
-                       s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->pleaf, s->pcum,
-                       s->merge_piece, s->ctot, S.T);
+  const size_t blds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)bt * 80;
+#define KX_LAUNCH_BACKLEN(MC, WD)                                                                                  \
+  hipLaunchKernelGGL((k_backlen<MC, WD>), dim3(grid), dim3(bt), blds, s->stream, s->in, s->n, s->seg, s->nblk, s->chk, \
+                     s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->prec,        \
+                     s->merge_piece, s->ctot, S.T)
+  if (s->Lc <= 32) { if (S.wide) KX_LAUNCH_BACKLEN(32, true); else KX_LAUNCH_BACKLEN(32, false); }
+  else { if (S.wide) KX_LAUNCH_BACKLEN(256, true); else KX_LAUNCH_BACKLEN(256, false); }
+#undef KX_LAUNCH_BACKLEN
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   if (!s->is_first) {  // the neighbouring rank needs our start leaf as a function of our end leaf
@@ -1172,8 +1207,12 @@ int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
                      s->bs_merged, s->bs_mstart, s->Lc, s->E, s->len, s->wsum);
   hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s->stream, s->ngroups, s->wsum, s->woff, s->flags);
   hipLaunchKernelGGL(k_scan_blocks, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, s->len, s->woff, s->off);
-  hipLaunchKernelGGL(k_fixtail, dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk, s->chk,
-                     s->E, s->len, s->merge_piece, s->ctot, s->pleaf, s->pcum, S.T);
+  if (S.wide)
+    hipLaunchKernelGGL((k_fixtail<true>), dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk,
+                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, S.T);
+  else
+    hipLaunchKernelGGL((k_fixtail<false>), dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk,
+                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   uint8_t e0 = 0;
@@ -1215,10 +1254,11 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   const uint32_t grid = (uint32_t)(want < (uint64_t)p->ncu ? want : (uint64_t)p->ncu);
   const size_t elds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)W * EMIT_WAVE_LDS;
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-#define KX_LAUNCH_EMIT(WV)                                                                                       \
-  hipLaunchKernelGGL((k_emit<WV>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
-                     s->pleaf, s->pcum, s->ctot, s->off, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
-  if (W == 16) KX_LAUNCH_EMIT(16); else if (W == 12) KX_LAUNCH_EMIT(12); else if (W == 8) KX_LAUNCH_EMIT(8); else KX_LAUNCH_EMIT(4);
+#define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
+  hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
+                     s->prec, s->ctot, s->off, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+  if (S.wide) { if (W == 16) KX_LAUNCH_EMIT(16, true); else if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
+  else { if (W == 16) KX_LAUNCH_EMIT(16, false); else if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }
 #undef KX_LAUNCH_EMIT
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());

@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--segment", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded protocol even with one rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the boundary hand-off")
+    ap.add_argument("--single-device", action="store_true", help="(validation) put every rank on cuda:0")
     a = ap.parse_args()
 
     import torch
@@ -78,13 +81,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if a.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+    comm_dev = dev if a.backend == "nccl" else "cpu"
     assert world == a.gpus, "launch with torch.distributed.run for --gpus > 1"
 
     blob = compile_file(a.program)
@@ -105,18 +116,21 @@ def main():
         n_local = L if rank < world - 1 else n_global - start
         off = start % len(base)
         reps = (off + n_local + len(base) - 1) // len(base)
-        t = tb.repeat(reps)[off:off + n_local].contiguous()
+        t = tb.repeat(reps)[off:off + n_local].clone()   # fresh (16-byte aligned) allocation holding exactly the shard
     out = torch.empty(int(n_local * 1.30) + (1 << 20), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    totals = {"out": None}
+
     def step():
-        if world == 1:
+        if not use_dist:
             return prog.run_device(t.data_ptr(), n_local, out.data_ptr(), out.numel(), stream)
         sh = prog.shard_begin(0, t.data_ptr(), n_local, rank == 0, rank == world - 1, stream)
-        res = sharded.raise_on_fail(sharded.run_stage_dist(sh, n_local, dev))
+        res = sharded.raise_on_fail(sharded.run_stage_dist(sh, n_local, comm_dev))
         sh.emit(out.data_ptr(), out.numel())
         prog.last_stats = sh.stats()
         sh.end()
+        totals["out"] = res[3]
         return res[1]
 
     def fence():
@@ -136,7 +150,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -146,6 +160,11 @@ def main():
         want = oracle.run(blob, base)
         head = bytes(out[:min(olen, 1 << 20)].cpu().numpy().tobytes())
         ok = head == want[:len(head)] if world == 1 or n_local >= len(base) else None
+        if ok and totals["out"] is not None and a.program in ("apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"):
+            # whole-job output length must equal that of the replicated base chunk (tiled_expected)
+            reps = n_global // len(base)
+            exp_total = (len(want) - 4 + 2) * (reps - 1) + len(want) if a.program == "apache_log" else len(want) * reps
+            ok = ok and totals["out"] == exp_total
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3

@@ -133,6 +133,18 @@ def test_many_simultaneous_paths():
     assert both(blob, b"a" * 31 + b"\n")[0] == ("fail", 31)
 
 
+def test_long_constants_use_the_wide_entry_form_and_oversize_pieces():
+    """Constants of ≥127 bytes escape to the wide side tables; a piece whose output exceeds the staging
+    buffer is written by its lane directly (both are rare paths with their own kernel instances)."""
+    big = "x" * 300
+    src = 'main := (~/a/ "%s" | /b/ | ~/c/ "<%s>")*\n' % (big, "y" * 130)
+    blob = blob_of(src)
+    for data in [b"a", b"abcab" * 50, b"b" * 1000 + b"a" + b"b" * 1000, b"c" * 64 + b"a" * 64, b"abc" * 3000]:
+        for seg in (64, 4096):
+            got, want = both(blob, data, segment_bytes=seg)
+            assert got == want, (len(data), seg)
+
+
 def test_multi_stage_pipeline_on_device():
     src = 'start: p >> a >> b\np := (~/abc/ "a")*\na := (/./ "b")*\nb := (/ab/ "c" | ~/[^ab]/ "lol")*\n'
     blob = blob_of(src)

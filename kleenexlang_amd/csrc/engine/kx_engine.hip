@@ -218,6 +218,26 @@ __device__ __forceinline__ void load_piece(const uint8_t* __restrict__ in, uint6
   }
 }
 
+// two pieces = one 128-byte line per lane and trip: lanes are a whole segment apart, so a line that is
+// only half consumed gets evicted from L2 before its other half is wanted (measured: 2x over-fetch)
+__device__ __forceinline__ void load_pair(const uint8_t* __restrict__ in, uint64_t n, uint64_t pstart, uint32_t (&wa)[16],
+                                          uint32_t (&wb)[16]) {
+  if (pstart + 2 * PIECE <= n) {
+    const uint4* p = reinterpret_cast<const uint4*>(in + pstart);
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wa[4 * i] = v[i].x; wa[4 * i + 1] = v[i].y; wa[4 * i + 2] = v[i].z; wa[4 * i + 3] = v[i].w;
+      wb[4 * i] = v[4 + i].x; wb[4 * i + 1] = v[4 + i].y; wb[4 * i + 2] = v[4 + i].z; wb[4 * i + 3] = v[4 + i].w;
+    }
+  } else {
+    load_piece(in, n, pstart, wa);
+    load_piece(in, n, pstart + PIECE, wb);
+  }
+}
+
 __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t nseg,
                           const uint64_t* __restrict__ seg_pos, const uint16_t* __restrict__ seg_state,
                           uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
@@ -268,16 +288,22 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
       // scattered 2-byte stores (each of which dirties a whole 64-byte sector)
       uint32_t cw[4];
       bool died = false;
-      static_for<0, 8>([&](auto pc) {
-        constexpr int k8 = decltype(pc)::value;
+      static_for<0, 4>([&](auto pc) {
+        constexpr int k2 = decltype(pc)::value;
         if (!died) {
-          if constexpr (k8 & 1) cw[k8 >> 1] |= h << 16; else cw[k8 >> 1] = h;
-          uint32_t w[16];
-          load_piece(in, n, pos, w);
-          const uint32_t h0 = h;
-          h = run_piece(w, h);
+          uint32_t wa[16], wb[16];
+          load_pair(in, n, pos, wa, wb);   // one full 128-byte line per lane
+          cw[k2] = h;
+          uint32_t h0 = h;
+          h = run_piece(wa, h);
           if (h == dead) { locate(h0); died = true; }
-          else pos += PIECE;
+          else {
+            pos += PIECE;
+            cw[k2] |= h << 16;
+            h0 = h;
+            h = run_piece(wb, h);
+            if (h == dead) { locate(h0); died = true; } else pos += PIECE;
+          }
         }
       });
       if (!died) *reinterpret_cast<uint4*>(chk + ((pos >> 6) - 8)) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
@@ -377,6 +403,17 @@ __device__ __forceinline__ void mask_tail(uint32_t (&bo)[BOW], int plen, uint32_
 // collapse to one as soon as they agree; from there on the per-piece end leaf and the running
 // output length are final and are written out for k_emit (pleaf/pcum).  Pieces above the merge
 // point (the block's tail) are finished by k_fixtail once the block's end leaf is known.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t walk_len(const uint32_t (&bo)[BOW], uint32_t& leaf, const Lds& L, const DevTables& T) {
+  uint32_t sum = 0;
+  static_for<0, PIECE>([&](auto ic) {
+    constexpr int t = PIECE - 1 - decltype(ic)::value;
+    const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+    const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
+  });
+  return sum;
+}
+
 template <int MAXC, bool WIDE>
 __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const Flags* flags, int is_last,
@@ -393,68 +430,79 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
   const uint32_t qe = (bend == n ? flags->end_state : chk[bend >> 6]) / (T.nclasses * 4);
+  // candidate 0 lives in registers (after merging it is the only one left); candidates 1.. in private memory
   uint16_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];   // cl = leaf·4
-  uint32_t nc, nact;
+  uint32_t nc, nact, leaf0, len0 = 0, pre0 = 0;
   uint32_t known = 0xFFFFFFFFu;
-  if (bend == n && is_last) { nc = 1; known = T.fin_leaf[qe]; cl[0] = (uint16_t)(known * 4); }
-  else { nc = T.nleaves[qe]; if (nc > MAXC) nc = MAXC; for (uint32_t j = 0; j < nc; ++j) cl[j] = (uint16_t)(j * 4); }
-  for (uint32_t j = 0; j < nc; ++j) { clen[j] = 0; pre[j] = 0; }
+  if (bend == n && is_last) { nc = 1; known = T.fin_leaf[qe]; leaf0 = known * 4; }
+  else {
+    nc = T.nleaves[qe]; if (nc > MAXC) nc = MAXC;
+    leaf0 = 0;
+    for (uint32_t j = 1; j < nc; ++j) { cl[j] = (uint16_t)(j * 4); clen[j] = 0; pre[j] = 0; }
+  }
   nact = nc;
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
   const uint64_t piece0 = bstart >> 6;
   const bool batch = (blk & (8 * PIECE - 1)) == 0;   // blocks start on an 8-piece boundary
   uint32_t mp = nact == 1 ? npieces : 0;   // pieces [mp, npieces) form the unresolved tail
-  for (uint32_t p = npieces; p-- > 0;) {
-    const uint64_t pstart = bstart + (uint64_t)p * PIECE;
-    const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
-    uint32_t w[16], bo[BOW];
-    load_piece(in, n, pstart, w);
-    // checkpoints arrive 8 at a time (k_forward stores them that way); the piece index is 8-aligned
-    // with the block, so group (p | 7) is fetched when the sweep first enters it
-    uint32_t hstart;
-    if (batch) {
-      if ((p & 7) == 7 || p == npieces - 1) lrec[4] = *reinterpret_cast<const uint4*>(chk + ((piece0 + p) & ~7ull));
-      hstart = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
-    } else hstart = chk[piece0 + p];
-    piece_forward(w, hstart, L, bo);
-    mask_tail(bo, plen, T.nullrow);
-    const bool final_here = nact == 1;
-    const uint32_t leaf_end = cl[0] >> 2;
-    for (uint32_t j = 0; j < nact; ++j) {
-      uint32_t leaf = cl[j], sum = 0;
-      static_for<0, PIECE>([&](auto ic) {
-        constexpr int t = PIECE - 1 - decltype(ic)::value;
-        const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
-        const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
-      });
-      cl[j] = (uint16_t)leaf; clen[j] += sum;
-    }
-    if (final_here) {
-      const PieceRec rec{(int32_t)(clen[0] - pre[0]), leaf_end};
-      if (batch) {
-        reinterpret_cast<PieceRec*>(lrec)[p & 7] = rec;
-        if ((p & 7) == 0) {   // records p..p+7 are complete (or belong to the unresolved tail: k_fixtail rewrites those)
-          uint4* dst = reinterpret_cast<uint4*>(prec + piece0 + p);
-          dst[0] = lrec[0]; dst[1] = lrec[1]; dst[2] = lrec[2]; dst[3] = lrec[3];
+  for (uint32_t pp = (npieces + 1) / 2; pp-- > 0;) {
+    uint32_t wa[16], wb[16];
+    load_pair(in, n, bstart + (uint64_t)pp * 2 * PIECE, wa, wb);
+#pragma unroll
+    for (int hf = 1; hf >= 0; --hf) {
+      const uint32_t p = 2 * pp + hf;
+      if (p < npieces) {
+        const uint32_t (&w)[16] = hf ? wb : wa;
+        const uint64_t pstart = bstart + (uint64_t)p * PIECE;
+        const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
+        uint32_t bo[BOW];
+        // checkpoints arrive 8 at a time (k_forward stores them that way); the piece index is 8-aligned
+        // with the block, so group (p | 7) is fetched when the sweep first enters it
+        uint32_t hstart;
+        if (batch) {
+          if ((p & 7) == 7 || p == npieces - 1) lrec[4] = *reinterpret_cast<const uint4*>(chk + ((piece0 + p) & ~7ull));
+          hstart = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
+        } else hstart = chk[piece0 + p];
+        piece_forward(w, hstart, L, bo);
+        mask_tail(bo, plen, T.nullrow);
+        if (nact == 1) {
+          const uint32_t leaf_end = leaf0 >> 2;
+          len0 += walk_len<WIDE>(bo, leaf0, L, T);
+          const PieceRec rec{(int32_t)(len0 - pre0), leaf_end};
+          if (batch) {
+            reinterpret_cast<PieceRec*>(lrec)[p & 7] = rec;
+            if ((p & 7) == 0) {   // records p..p+7 are complete (or belong to the unresolved tail: k_fixtail rewrites those)
+              uint4* dst = reinterpret_cast<uint4*>(prec + piece0 + p);
+              dst[0] = lrec[0]; dst[1] = lrec[1]; dst[2] = lrec[2]; dst[3] = lrec[3];
+            }
+          } else prec[piece0 + p] = rec;
+        } else {
+          len0 += walk_len<WIDE>(bo, leaf0, L, T);
+          bool same = true;
+          for (uint32_t j = 1; j < nact; ++j) {
+            uint32_t lf = cl[j];
+            clen[j] += walk_len<WIDE>(bo, lf, L, T);
+            cl[j] = (uint16_t)lf;
+            same = same && lf == leaf0;
+          }
+          if (same) { pre0 = len0; for (uint32_t j = 1; j < nc; ++j) pre[j] = clen[j]; nact = 1; mp = p; }
         }
-      } else prec[piece0 + p] = rec;
-    } else {
-      bool same = true;
-      for (uint32_t j = 1; j < nact; ++j) same = same && cl[j] == cl[0];
-      if (same) { for (uint32_t j = 0; j < nc; ++j) pre[j] = clen[j]; nact = 1; mp = p; }
+      }
     }
   }
   const bool merged = nact == 1;
-  const uint32_t tail = clen[0] - pre[0];
+  const uint32_t tail = len0 - pre0;
   if (known != 0xFFFFFFFFu) {
-    bs_start[(size_t)m * Lc + known] = (uint8_t)(cl[0] >> 2); bs_len[(size_t)m * Lc + known] = clen[0];
-  } else if (merged) {  // after merging only candidate 0 kept accumulating
-    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = (uint8_t)(cl[0] >> 2); bs_len[(size_t)m * Lc + j] = pre[j] + tail; }
+    bs_start[(size_t)m * Lc + known] = (uint8_t)(leaf0 >> 2); bs_len[(size_t)m * Lc + known] = len0;
   } else {
-    for (uint32_t j = 0; j < nc; ++j) { bs_start[(size_t)m * Lc + j] = (uint8_t)(cl[j] >> 2); bs_len[(size_t)m * Lc + j] = clen[j]; }
+    bs_start[(size_t)m * Lc] = (uint8_t)(leaf0 >> 2); bs_len[(size_t)m * Lc] = len0;
+    for (uint32_t j = 1; j < nc; ++j) {   // after merging only candidate 0 kept accumulating
+      bs_start[(size_t)m * Lc + j] = (uint8_t)((merged ? leaf0 : (uint32_t)cl[j]) >> 2);
+      bs_len[(size_t)m * Lc + j] = merged ? pre[j] + tail : clen[j];
+    }
   }
   bs_merged[m] = merged ? 1 : 0;
-  bs_mstart[m] = (uint8_t)(cl[0] >> 2);
+  bs_mstart[m] = (uint8_t)(leaf0 >> 2);
   merge_piece[m] = (uint16_t)(merged ? mp : 0);
   ctot[m] = merged ? tail : 0;
 }
@@ -585,13 +633,7 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     piece_forward(w, chk[pstart >> 6], L, bo);
     mask_tail(bo, plen, T.nullrow);
     const uint32_t leaf_end = leaf >> 2;
-    uint32_t sum = 0;
-    static_for<0, PIECE>([&](auto ic) {
-      constexpr int t = PIECE - 1 - decltype(ic)::value;
-      const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
-      const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
-    });
-    suffix += sum;
+    suffix += walk_len<WIDE>(bo, leaf, L, T);
     prec[piece0 + p] = PieceRec{base + (int32_t)suffix, leaf_end};
   }
 }

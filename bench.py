@@ -176,6 +176,13 @@ def main():
         alg = {"sync": 0.0, "forward": 1.0, "head": 0.0, "backlen": 1.0, "resolve": 0.0, "emit": 1.0 + ratio}
         achieved = alg[dom] * n_local / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
         ksum = sum(kern.values())
+        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if a.program == "apache_log" and abs(tj["input_bytes"] - n_local) < (1 << 20):
+                traffic = tj["per_launch"]["k_" + dom]["total"]
+        except Exception:
+            traffic = None
         line = {
             "metric": "input GB/s + % HBM-read roofline, apache_log.kex over 10 GiB synthetic log",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -186,7 +193,7 @@ def main():
                        "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or "auto (4-16 KiB by input size)",
                        "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_input_byte": alg[dom]},
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
             "input_read_roofline": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,

@@ -12,19 +12,19 @@
 //   per-step suffixes along that path, written at prefix-summed offsets.  No register bytes ever
 //   move; results are bit-identical to the register form (tests/).
 //
-// Kernels (one lane = one `segment` of the input, tables staged in LDS):
+// Kernels (table image staged in LDS; DESIGN.md §3 has the layout and the byte accounting):
 //   k_sync     start state of every segment: run the compile-time synchronising automaton from the
 //              segment start until every possible start state has converged (speculation resolved
 //              without enumerating states at run time)
-//   k_forward  state sequence from the sync point; one state checkpoint per 64-byte piece; failure
-//              position (first symbol without transition) by atomicMin
+//   k_forward  lane = segment: state sequence from the sync point; one state checkpoint per 64-byte
+//              piece; failure position (first symbol without transition) by atomicMin
 //   k_head     (sharded runs) the few leading bytes of a shard that need the previous shard's state
-//   k_backlen  per block: output length and start leaf for every candidate end leaf (candidates
-//              merge after about one record)
-//   k_resolve  end leaf per block from its successor's summary; block-level exclusive scan of the
-//              output lengths (k_scan_*)
-//   k_emit     per block: re-derive the piece, walk it backward along the resolved path and write
-//              the output bytes at the block's offset
+//   k_backlen  lane = block: output length and start leaf for every candidate end leaf (candidates
+//              merge after about one record); per-piece {running length, end leaf} records
+//   k_resolve  end leaf per block from its successor's summary; exclusive scan of the block output
+//              lengths (k_scan_*); k_fixtail re-walks the few pieces above each block's merge point
+//   k_emit     lane = piece, persistent: re-derive the piece, walk it backward along the resolved
+//              path, assemble the wave's contiguous output in LDS, flush with 16-byte stores
 // DESIGN.md has the data layout, the byte accounting and the roofline for each.
 #include <hip/hip_runtime.h>
 #include <unistd.h>

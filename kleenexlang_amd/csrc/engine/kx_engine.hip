@@ -27,6 +27,7 @@
 //              path, assemble the wave's contiguous output in LDS, flush with 16-byte stores
 // DESIGN.md has the data layout, the byte accounting and the roofline for each.
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -1405,27 +1406,92 @@ int kx_run_host(kx_program* p, const void* in, size_t n, void** out, size_t* out
 
 void kx_host_free(void* p) { free(p); }
 
+// stdin → pinned host → HBM → engine → pinned host → stdout.  Reads and H2D copies overlap (two
+// pinned staging buffers), and so do D2H copies and writes.  The whole input is resident in HBM
+// while the engine runs (SURVEY §8f rank 1 asks for windowed streaming on top; not built yet).
 int kx_run_fd(kx_program* p, int in_fd, int out_fd, kx_stats* stats) {
-  std::vector<char> buf;
-  size_t n = 0;
-  for (;;) {
-    if (buf.size() - n < (1u << 20)) buf.resize(buf.size() ? buf.size() * 2 : (4u << 20));
-    ssize_t r = read(in_fd, buf.data() + n, buf.size() - n);
-    if (r < 0) { if (errno == EINTR) continue; return setErr(KX_E_IO, "read failed"); }
-    if (r == 0) break;
-    n += (size_t)r;
+  if (!p) return setErr(KX_E_ARG, "null argument");
+  const size_t CH = 64u << 20;
+  char* pin[2] = {nullptr, nullptr};
+  hipEvent_t ev[2];
+  hipStream_t cs = nullptr;
+  char* d_in = nullptr; size_t dcap = 0, n = 0;
+  void* d_out = nullptr;
+  int rc = 0;
+  auto cleanup = [&]() {
+    for (int k = 0; k < 2; ++k) { if (pin[k]) (void)hipHostFree(pin[k]); }
+    if (cs) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipStreamDestroy(cs); }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+  };
+#define KX_FD_CHECK(expr) do { if ((expr) != hipSuccess) { cleanup(); return setErr(KX_E_HIP, #expr " failed"); } } while (0)
+  KX_FD_CHECK(hipStreamCreate(&cs));
+  KX_FD_CHECK(hipEventCreate(&ev[0])); KX_FD_CHECK(hipEventCreate(&ev[1]));
+  KX_FD_CHECK(hipHostMalloc((void**)&pin[0], CH, hipHostMallocDefault));
+  KX_FD_CHECK(hipHostMalloc((void**)&pin[1], CH, hipHostMallocDefault));
+  struct stat stt;
+  if (fstat(in_fd, &stt) == 0 && S_ISREG(stt.st_mode)) {   // regular file: size known up front
+    off_t pos = lseek(in_fd, 0, SEEK_CUR);
+    if (pos >= 0 && stt.st_size > pos) dcap = (size_t)(stt.st_size - pos) + 16;
   }
-  void* out = nullptr; size_t ol = 0;
-  int rc = kx_run_host(p, buf.data(), n, &out, &ol, stats);
+  if (dcap == 0) dcap = 4 * CH;
+  KX_FD_CHECK(hipMalloc((void**)&d_in, dcap));
+  for (int k = 0;; k ^= 1) {
+    KX_FD_CHECK(hipEventSynchronize(ev[k]));   // the previous copy out of this staging buffer is done
+    size_t got = 0;
+    while (got < CH) {
+      ssize_t r = read(in_fd, pin[k] + got, CH - got);
+      if (r < 0) { if (errno == EINTR) continue; cleanup(); return setErr(KX_E_IO, "read failed"); }
+      if (r == 0) break;
+      got += (size_t)r;
+    }
+    if (got == 0) break;
+    if (n + got > dcap) {   // pipe of unknown length: grow geometrically
+      size_t ncap = dcap * 2 > n + got ? dcap * 2 : n + got + CH;
+      char* nd = nullptr;
+      KX_FD_CHECK(hipMalloc((void**)&nd, ncap));
+      KX_FD_CHECK(hipStreamSynchronize(cs));
+      KX_FD_CHECK(hipMemcpy(nd, d_in, n, hipMemcpyDeviceToDevice));
+      (void)hipFree(d_in); d_in = nd; dcap = ncap;
+    }
+    KX_FD_CHECK(hipMemcpyAsync(d_in + n, pin[k], got, hipMemcpyHostToDevice, cs));
+    KX_FD_CHECK(hipEventRecord(ev[k], cs));
+    n += got;
+    if (got < CH) break;
+  }
+  KX_FD_CHECK(hipStreamSynchronize(cs));
+  size_t ol = 0;
+  rc = runPipeline(p, d_in, n, nullptr, 0, true, &d_out, &ol, stats, nullptr);
   if (rc == 0) {
-    size_t w = 0;
-    while (w < ol) {
-      ssize_t r = write(out_fd, (char*)out + w, ol - w);
-      if (r < 0) { if (errno == EINTR) continue; free(out); return setErr(KX_E_IO, "write failed"); }
-      w += (size_t)r;
+    size_t done = 0, issued = 0;
+    size_t clen[2] = {0, 0};
+    int k = 0;
+    if (issued < ol) {
+      clen[0] = ol - issued < CH ? ol - issued : CH;
+      KX_FD_CHECK(hipMemcpyAsync(pin[0], (char*)d_out + issued, clen[0], hipMemcpyDeviceToHost, cs));
+      KX_FD_CHECK(hipEventRecord(ev[0], cs));
+      issued += clen[0];
+    }
+    while (done < ol) {
+      if (issued < ol) {   // next chunk flies while this one is written
+        clen[k ^ 1] = ol - issued < CH ? ol - issued : CH;
+        KX_FD_CHECK(hipMemcpyAsync(pin[k ^ 1], (char*)d_out + issued, clen[k ^ 1], hipMemcpyDeviceToHost, cs));
+        KX_FD_CHECK(hipEventRecord(ev[k ^ 1], cs));
+        issued += clen[k ^ 1];
+      }
+      KX_FD_CHECK(hipEventSynchronize(ev[k]));
+      size_t w = 0;
+      while (w < clen[k]) {
+        ssize_t r = write(out_fd, pin[k] + w, clen[k] - w);
+        if (r < 0) { if (errno == EINTR) continue; cleanup(); return setErr(KX_E_IO, "write failed"); }
+        w += (size_t)r;
+      }
+      done += clen[k];
+      k ^= 1;
     }
   }
-  free(out);
+#undef KX_FD_CHECK
+  cleanup();
   return rc;
 }
 

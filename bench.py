@@ -117,7 +117,8 @@ def main():
         off = start % len(base)
         reps = (off + n_local + len(base) - 1) // len(base)
         t = tb.repeat(reps)[off:off + n_local].clone()   # fresh (16-byte aligned) allocation holding exactly the shard
-    out = torch.empty(int(n_local * 1.30) + (1 << 20), dtype=torch.uint8, device=dev)
+    expansion = {"apache_log": 1.30, "csv2json": 2.05, "iso_datetime_to_json": 4.35, "thousand_sep": 1.40}[a.program]
+    out = torch.empty(int(n_local * expansion) + (1 << 20), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     totals = {"out": None}

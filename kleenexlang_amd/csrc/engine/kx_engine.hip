@@ -59,6 +59,7 @@ constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
 constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
 constexpr int EMIT_JCAP = 384;            // k_emit: constant-copy jobs per wave round
+constexpr int EMIT_INLINE = 2;            // k_emit: constants up to this length are written in place, not listed
 constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JCAP * 8;
 
 // ------------------------------------------------------------------ device-side program view
@@ -648,13 +649,15 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
 // flushes it with aligned 16-byte stores.  Persistent workgroups: tables are staged once per CU.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
-template <int WAVES, bool WIDE>
+template <int WAVES, int MODE>   // MODE 0: plain; 1: wide back entries; 2: every constant ≤ EMIT_INLINE bytes → written in place
 __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
                                                      const unsigned long long* __restrict__ off, uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
+  constexpr bool WIDE = MODE == 1;
+  constexpr bool INL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
         bo_set(bo, t, a);
         const uint32_t dl = ent_dlen<WIDE>(e, a, L, T);
         olen += dl;
-        nj += dl > E_COPY(e) ? 1u : 0u;
+        nj += !INL && dl > E_COPY(e) ? 1u : 0u;
         leaf = E_LEAF4(e);
         tie(leaf, olen); tie(leaf, nj);
       });
@@ -743,7 +746,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
             const uint32_t e = e8[i];
             const uint32_t cp = E_COPY(e), dl = ent_dlen<WIDE>(e, a8[i], L, T);
             if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, e);
-            if (dl > cp) { jobs[2 * ji] = (o + cp) | ((dl - cp) << 16); jobs[2 * ji + 1] = ent_off<WIDE>(e, a8[i], L, T); ++ji; }
+            if (dl > cp) {
+              const uint32_t cl = dl - cp, src = ent_off<WIDE>(e, a8[i], L, T);
+              if (INL) {   // a program whose constants are all one or two bytes: cheaper in place than as jobs
+                stg[o + cp] = L.pb(src);
+                if (cl == 2) stg[o + cp + 1] = L.pb(src + 1);
+              } else { jobs[2 * ji] = (o + cp) | (cl << 16); jobs[2 * ji + 1] = src; ++ji; }
+            }
             o += dl;
           });
         });
@@ -790,6 +799,7 @@ struct Stage {
   size_t lds_bytes = 0;                                // packed table image
   size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
   bool wide = false;                                   // some back entry needs the escaped wide form
+  bool short_consts = true;                            // every path constant is at most EMIT_INLINE bytes
 };
 
 struct Arena {  // grow-only device workspace, reused across runs
@@ -881,6 +891,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
     const bool wide = dlen >= 127 || poff >= (1u << 14);
     if (wide) S.wide = true;
+    if (dlen - copy > (uint32_t)EMIT_INLINE) S.short_consts = false;
     ent.push_back((parent * 4) | (copy << 10) | ((wide ? 127u : dlen) << 11) | ((wide ? 0u : poff) << 18));
     wlen.push_back(dlen); woff.push_back(poff);
   };
@@ -1041,7 +1052,7 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   const size_t elds = tab + (size_t)p->emit_waves * EMIT_WAVE_LDS;
   bool anywide = false;
   for (auto& s : p->stages) anywide = anywide || s.wide;
-#define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, false>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, true>, elds) : 0))
+#define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, 0>, elds), rc = rc ? rc : setLds((const void*)k_emit<WV, 2>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, 1>, elds) : 0))
   rc = p->emit_waves == 16 ? KX_EMIT_ATTR(16) : p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
 #undef KX_EMIT_ATTR
   if (rc) { kx_free(p); return rc; }
@@ -1300,8 +1311,10 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
                      s->prec, s->ctot, s->off, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
-  if (S.wide) { if (W == 16) KX_LAUNCH_EMIT(16, true); else if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
-  else { if (W == 16) KX_LAUNCH_EMIT(16, false); else if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }
+  const int mode = S.wide ? 1 : S.short_consts ? 2 : 0;
+  if (mode == 1) { if (W == 16) KX_LAUNCH_EMIT(16, 1); else if (W == 12) KX_LAUNCH_EMIT(12, 1); else if (W == 8) KX_LAUNCH_EMIT(8, 1); else KX_LAUNCH_EMIT(4, 1); }
+  else if (mode == 2) { if (W == 16) KX_LAUNCH_EMIT(16, 2); else if (W == 12) KX_LAUNCH_EMIT(12, 2); else if (W == 8) KX_LAUNCH_EMIT(8, 2); else KX_LAUNCH_EMIT(4, 2); }
+  else { if (W == 16) KX_LAUNCH_EMIT(16, 0); else if (W == 12) KX_LAUNCH_EMIT(12, 0); else if (W == 8) KX_LAUNCH_EMIT(8, 0); else KX_LAUNCH_EMIT(4, 0); }
 #undef KX_LAUNCH_EMIT
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());

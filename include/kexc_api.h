@@ -34,6 +34,11 @@ int kexc_compile(const char* source, size_t source_len, const char* source_name,
 int kexc_emit_c(const char* source, size_t source_len, const char* source_name, int opt_level,
                 char** c_text, size_t* c_len);
 
+/* Test support: the nondeterministic transducers (one per pipeline stage, after
+ * constructTransducer, src/KMC/SymbolicFST/Transducer.hs:57-107) as JSON:
+ * [{"nstates","init","final":[..],"eps":[[ [[out bytes],to], ..] per state],"sym":[[ [[[lo,hi],..],copy,to], ..] per state]}] */
+int kexc_dump_fst(const char* source, size_t source_len, const char* source_name, char** json, size_t* json_len);
+
 const char* kexc_last_error(void);
 void kexc_free(void* p);
 

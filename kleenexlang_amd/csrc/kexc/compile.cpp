@@ -74,6 +74,58 @@ int kexc_emit_c(const char* source, size_t source_len, const char* source_name, 
   }
 }
 
+// The nondeterministic transducer of every pipeline stage as JSON — for tests that simulate the FST
+// directly (an evaluation route that shares nothing with determinization, lowering or the engines).
+int kexc_dump_fst(const char* source, size_t source_len, const char* source_name, char** json, size_t* json_len) {
+  try {
+    std::string name = source_name ? source_name : "<memory>";
+    kexc::Prog ast = kexc::parseKleenex(std::string(source, source_len), name);
+    kexc::RProg rp = kexc::desugar(ast);
+    std::ostringstream o;
+    o << "[";
+    for (size_t si = 0; si < rp.pipeline.size(); ++si) {
+      kexc::FST f = kexc::constructTransducer(rp, rp.pipeline[si]);
+      o << (si ? "," : "") << "{\"nstates\":" << f.nstates << ",\"init\":" << f.init << ",\"final\":[";
+      bool first = true;
+      for (int q = 0; q < f.nstates; ++q) if (f.is_final[q]) { o << (first ? "" : ",") << q; first = false; }
+      o << "],\"eps\":[";
+      for (int q = 0; q < f.nstates; ++q) {
+        o << (q ? "," : "") << "[";
+        for (size_t k = 0; k < f.eps[q].size(); ++k) {
+          o << (k ? "," : "") << "[[";
+          for (size_t b = 0; b < f.eps[q][k].out.size(); ++b) o << (b ? "," : "") << (int)(unsigned char)f.eps[q][k].out[b];
+          o << "]," << f.eps[q][k].to << "]";
+        }
+        o << "]";
+      }
+      o << "],\"sym\":[";
+      for (int q = 0; q < f.nstates; ++q) {
+        o << (q ? "," : "") << "[";
+        for (size_t k = 0; k < f.sym[q].size(); ++k) {
+          o << (k ? "," : "") << "[[";
+          bool fr = true;
+          for (int b = 0; b < 256;) {
+            if (!f.sym[q][k].pred.has(b)) { ++b; continue; }
+            int e = b; while (e + 1 < 256 && f.sym[q][k].pred.has(e + 1)) ++e;
+            o << (fr ? "" : ",") << "[" << b << "," << e << "]"; fr = false; b = e + 1;
+          }
+          o << "]," << (f.sym[q][k].copy ? 1 : 0) << "," << f.sym[q][k].to << "]";
+        }
+        o << "]";
+      }
+      o << "]}";
+    }
+    o << "]";
+    std::string txt = o.str();
+    *json = dupBytes(txt.data(), txt.size());
+    *json_len = txt.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 const char* kexc_last_error(void) { return g_err.c_str(); }
 void kexc_free(void* p) { free(p); }
 

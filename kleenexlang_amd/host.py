@@ -166,6 +166,24 @@ def emit_c(source, name="<memory>", opt=3):
         lib.kexc_free(txt)
 
 
+def dump_fst(source, name="<memory>"):
+    """JSON-decoded nondeterministic transducers of a program (test support)."""
+    import json
+    lib = load_compiler()
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    txt = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    lib.kexc_dump_fst.argtypes = lib.kexc_compile.argtypes[:3] + lib.kexc_compile.argtypes[4:]
+    rc = lib.kexc_dump_fst(source, len(source), name.encode(), ctypes.byref(txt), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return json.loads(ctypes.string_at(txt, n.value).decode("utf-8"))
+    finally:
+        lib.kexc_free(txt)
+
+
 def program_path(name):
     p = os.path.join(PROGRAM_DIR, name if name.endswith(".kex") else name + ".kex")
     if not os.path.exists(p):

@@ -1,0 +1,102 @@
+"""Three independent evaluation routes must agree on random programs and inputs:
+  lock-step simulation of the nondeterministic transducer (oracle/fst_sim.py, the reference's
+  `--sim=lockstep` semantics), the register form run like generated C + crt.c, and the path form.
+On the GPU the HIP engine joins them."""
+import pytest
+import randprog
+from conftest import blob_of
+
+from kleenexlang_amd import CompileError, host
+from oracle import fst_sim, oracle
+
+NPROG = 120
+
+
+def _usable(src):
+    """Compiles, and the path-tree SST stays small (a few generated nestings blow up to 10^4 states,
+    where the restated `optimize` pass takes minutes — as the reference's would)."""
+    try:
+        return oracle.info(blob_of(src, 0))["nstates"] <= 2000
+    except CompileError:
+        return False
+
+
+def _cpu_results(src, data):
+    fsts = host.dump_fst(src)
+    want = fst_sim.run(fsts, data)
+    got = []
+    for opt in (0, 3):
+        blob = blob_of(src, opt)
+        for pf in (False, True):
+            try:
+                got.append(oracle.run(blob, data, path_form=pf))
+            except oracle.OracleMatchError:
+                got.append(None)
+    return want, got
+
+
+def test_random_programs_three_routes_agree():
+    checked = accepted = 0
+    for seed in range(NPROG):
+        src = randprog.program(seed)
+        if not _usable(src):
+            continue
+        for data in randprog.inputs(seed, 12, 24):
+            want, got = _cpu_results(src, data)
+            assert all(g == want for g in got), (seed, src, data, want, got)
+            checked += 1
+            accepted += want is not None
+    assert checked > 1000 and accepted > 100, (checked, accepted)
+
+
+def test_random_programs_failure_position_is_first_dead_prefix():
+    """count in "Match error at input symbol <count>" = length of the longest prefix that still has a live path."""
+    for seed in range(0, NPROG, 3):
+        src = randprog.program(seed)
+        if not _usable(src):
+            continue
+        blob = blob_of(src, 3)
+        fst = host.dump_fst(src)[0]
+        for data in randprog.inputs(seed, 6, 16):
+            try:
+                oracle.run(blob, data)
+                continue
+            except oracle.OracleMatchError as e:
+                pos = e.pos
+            # a live path exists for data[:pos] (the run got that far) …
+            paths = fst_sim._close(fst, [(b"", fst["init"])])
+            for b in data[:pos]:
+                paths = fst_sim._close(fst, [(a, t) for a, q in paths for rg, cp, t in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)])
+            assert paths, (seed, data, pos)
+            if pos < len(data):   # … and none survives the next symbol
+                b = data[pos]
+                nxt = [(a, t) for a, q in paths for rg, cp, t in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)]
+                assert not fst_sim._close(fst, nxt), (seed, data, pos)
+
+
+@pytest.mark.gpu
+def test_random_programs_on_the_engine():
+    from kleenexlang_amd import MatchError, Program
+    n = 0
+    for seed in range(0, NPROG, 2):
+        src = randprog.program(seed)
+        if not _usable(src):
+            continue
+        blob = blob_of(src, 3)
+        try:
+            p = Program(blob, segment_bytes=64)
+        except Exception:
+            continue   # tables beyond the engine's documented limits
+        for data in randprog.inputs(seed, 6, 200):
+            try:
+                want = oracle.run(blob, data)
+            except oracle.OracleMatchError as e:
+                want = ("fail", e.pos)
+            try:
+                got = p.run_host(data)
+            except MatchError as e:
+                got = ("fail", e.pos)
+            assert got == want, (seed, src, data)
+            n += 1
+        p.close()
+    assert n > 200

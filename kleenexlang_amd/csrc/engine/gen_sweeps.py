@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Writes kx_sweeps.inc: the two fully unrolled, hand-scheduled gfx950 instruction sequences of the
+engine's per-piece work, as inline-asm functions.
+
+Both run TWO independent dependency chains per lane (the two 32-byte halves of a 64-byte piece), so
+that one chain's LDS round trip hides behind the other's, and both issue the next dependent LDS read
+before doing the bookkeeping of the current step.
+
+  piece_forward2(w, hA, hB, himask) -> bo[32]
+      forward re-derivation of the back rows: chain A = bytes 0..31 from state handle hA,
+      chain B = bytes 32..63 from hB.  Per byte and chain: 1 SDWA shift (class address), 1 ds_read_u16
+      (class*4), 1 SDWA add on the chain (next fwd address = e.lo16 + class*4), 1 ds_read_b32, 1 op
+      packing the row offset (e.hi16) into bo.  The class table sits at LDS address 0.
+
+  piece_sweep2(bo, w, leafA, oA, leafB, oB, jp, js, jl)
+      backward sweep that places the output: chain A = steps 63..32 from (leafA, oA), chain B = steps
+      31..0 from (leafB, oB); see the step description in kx_engine.hip (k_emit).
+
+The file is generated (python gen_sweeps.py > kx_sweeps.inc) and committed; build.py regenerates it
+when this script is newer.
+"""
+import sys
+
+SD = "dst_sel:DWORD dst_unused:UNUSED_PAD"
+
+
+def fwd2():
+    L = []
+    ap = L.append
+    # rotating registers: e{A,B}{0,1} fwd words, c{A,B}{0,1,2} classes (prefetch distance 2), x{A,B} class addresses
+    def cls_issue(ch, t, slot):
+        wi, by = t >> 2, t & 3
+        ap("v_lshlrev_b32_sdwa %%[x%s], 1, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (ch, wi, SD, by))
+        ap("ds_read_u16 %%[c%s%d], %%[x%s]" % (ch, slot, ch))
+    base = {"A": 0, "B": 32}
+    for d in (0, 1):
+        for ch in "AB":
+            cls_issue(ch, base[ch] + d, d)
+    ap("s_waitcnt lgkmcnt(2)")          # classes of step 0 (both chains) have arrived
+    for ch in "AB":
+        ap("v_add_u32 %%[a%s], %%[h%s], %%[c%s0]" % (ch, ch, ch))
+        ap("ds_read_b32 %%[e%s0], %%[a%s]" % (ch, ch))
+    for j in range(32):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 2 < 32:
+            for ch in "AB":
+                cls_issue(ch, base[ch] + j + 2, (j + 2) % 3)
+        ap("s_waitcnt lgkmcnt(%d)" % (2 if j + 2 < 32 else 0))   # e_j of both chains (and class j+1) are in
+        if j + 1 < 32:
+            for ch in "AB":
+                ap("v_add_u32_sdwa %%[a%s], %%[e%s%d], %%[c%s%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (ch, ch, cur, ch, (j + 1) % 3, SD))
+                ap("ds_read_b32 %%[e%s%d], %%[a%s]" % (ch, nxt, ch))
+        for ch in "AB":
+            t = base[ch] + j
+            if t & 1:
+                ap("v_and_or_b32 %%[bo%d], %%[e%s%d], %%[hm], %%[bo%d]" % (t >> 1, ch, cur, t >> 1))
+            else:
+                ap("v_lshrrev_b32 %%[bo%d], 16, %%[e%s%d]" % (t >> 1, ch, cur))
+    return L
+
+
+def sweep2():
+    L = []
+    ap = L.append
+    row = lambda t: "%%[bo%d]" % (t >> 1)
+    wsel = lambda t: "WORD_%d" % (t & 1)
+    base = {"A": 32, "B": 0}
+    for ch in "AB":
+        t = base[ch] + 31
+        ap("v_add_u32_sdwa %%[a%s0], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, row(t), ch, SD, wsel(t)))
+        ap("ds_read_b32 %%[e%s0], %%[a%s0]" % (ch, ch))
+    for j in range(31, -1, -1):
+        cur, nxt = (31 - j) & 1, (32 - j) & 1
+        ap("s_waitcnt lgkmcnt(0)")
+        for ch in "AB":
+            ap("v_and_b32 %%[leaf%s], 0x3fc, %%[e%s%d]" % (ch, ch, cur))
+            if j > 0:
+                t = base[ch] + j - 1
+                ap("v_add_u32_sdwa %%[a%s%d], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, nxt, row(t), ch, SD, wsel(t)))
+                ap("ds_read_b32 %%[e%s%d], %%[a%s%d]" % (ch, nxt, ch, nxt))
+        for ch in "AB":
+            t = base[ch] + j
+            e, a, o = "%%[e%s%d]" % (ch, cur), "%%[a%s%d]" % (ch, cur), "%%[o%s]" % ch
+            by = t & 3
+            if by == 3:
+                ap("v_lshrrev_b32 %%[tw%s], 8, %%[w%d]" % (ch, t >> 2))
+            src = "%%[tw%s]" % ch if by in (1, 3) else "%%[w%d]" % (t >> 2)
+            wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            ap("v_sub_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, e, SD))
+            ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % e)
+            ap("v_lshl_or_b32 %s, %s, 31, %s" % (e, e, o))
+            ap("%s %s, %s" % (wr, e, src))
+            ap("s_and_saveexec_b64 %[sv], vcc")
+            ap("s_cbranch_execz 1f")
+            ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
+            ap("ds_write_b32 %%[jp], %s" % a)
+            ap("v_add_u32 %[jp], %[js], %[jp]")
+            ap("v_min_u32 %[jp], %[jp], %[jl]")
+            ap("1:")
+            ap("s_or_b64 exec, exec, %[sv]")
+    return L
+
+
+def emit_fn(out, name, sig, decl, lines, outs, ins, clob):
+    out.write("__device__ __forceinline__ void %s(%s) {\n" % (name, sig))
+    if decl:
+        out.write("  %s\n" % decl)
+    out.write("  asm volatile(\n")
+    for ln in lines:
+        out.write('      "%s\\n"\n' % ln)
+    out.write("      : %s\n      : %s\n      : %s);\n}\n\n" % (", ".join(outs), ", ".join(ins), clob))
+
+
+def main():
+    out = sys.stdout
+    out.write("// kx_sweeps.inc — GENERATED by gen_sweeps.py; do not edit.  See that script for the schedule.\n\n")
+    tmp = ["eA0", "eA1", "eB0", "eB1", "cA0", "cA1", "cA2", "cB0", "cB1", "cB2", "xA", "xB", "aA", "aB"]
+    emit_fn(out, "piece_forward2",
+            "const uint32_t (&w)[16], uint32_t hA, uint32_t hB, uint32_t himask, uint32_t (&bo)[32]",
+            "uint32_t " + ", ".join(tmp) + ";",
+            fwd2(),
+            ['[bo%d] "=&v"(bo[%d])' % (i, i) for i in range(32)] + ['[%s] "=&v"(%s)' % (t, t) for t in tmp],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[hA] "v"(hA)', '[hB] "v"(hB)', '[hm] "s"(himask)'],
+            '"memory"')
+    tmp = ["eA0", "eA1", "eB0", "eB1", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
+    emit_fn(out, "piece_sweep2",
+            "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
+            "uint32_t& jp, uint32_t js, uint32_t jl",
+            "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
+            sweep2(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
+                                                       '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jp] "+v"(jp)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
+            ['[js] "v"(js)', '[jl] "v"(jl)'],
+            '"vcc", "memory"')
+
+
+if __name__ == "__main__":
+    main()

@@ -54,27 +54,34 @@ int setErr(int code, const std::string& m) { g_err = m; return code; }
       return setErr(KX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
   } while (0)
 
-constexpr int PIECE = 64;                 // bytes between state checkpoints
+constexpr int PIECE = 64;                 // bytes per lane-step of the backward kernels (one piece record each)
+constexpr int HALF = 32;                  // bytes between state checkpoints (two dependency chains per piece)
+constexpr uint32_t OFF_FWD = 512;         // the table image starts with the 512-byte class table; state rows follow
 constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
 constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
-constexpr int EMIT_JCAP = 384;            // k_emit: constant-copy jobs per wave round
 constexpr int EMIT_INLINE = 2;            // k_emit: constants up to this length are written in place, not listed
-constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JCAP * 8;
+constexpr int EMIT_JOBS = 4096;           // k_emit: bytes of constant-copy job slots per wave (4 B each, shared out among a round's lanes)
+constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JOBS;
 
 // ------------------------------------------------------------------ device-side program view
 // The table image is copied verbatim into LDS (at LDS address 0 of the dynamic segment) and is
 // addressed by *byte offsets* that are stored pre-scaled inside the tables themselves, so that a
 // lookup is one add + one ds_read:
-//   state handle h   = byte offset of the state's row in fwd          (h = state·C·4)
+//   state handle h   = byte offset of the state's row in the image     (h = off_fwd + state·C·4)
 //   cls4[byte]       = class·4                                        (u16 table)
 //   e = fwd[h + cls4[b]] :  low 16 = next handle, high 16 = byte offset of the transition's back row
-//   back entry x = ent[row + leaf·4] : leaf'·4 (10 bits) | copy (1) | appended bytes (7) | pool offset (14)
+//   back entry x = ent[row + leaf·4] :
+//     bit 0 "no input byte copied" | bits 2-9 leaf' (so x & 0x3FC = leaf'·4) | bits 10-22 pool offset |
+//     bit 23 "a constant follows" | bits 24-30 appended bytes (copy included); bit 31 = 0
 //     appended = 127 escapes to the wide side tables wlen/woff (global memory) for long constants.
+//   The layout serves k_emit's step: the byte count is a whole byte (SDWA operand), bit 0 shifted to
+//   bit 31 turns the staging address of a step that copies nothing into an out-of-range LDS address
+//   (the hardware drops such stores), and bit 23 is the sign of byte 2 (one SDWA compare).
 struct DevTables {
-  const uint32_t* packed;     // [fwd | ent | pool | cls4] image
+  const uint32_t* packed;     // [cls4 | fwd | ent | pool] image
   uint32_t packed_words;
-  uint32_t off_ent, off_pool, off_cls;  // byte offsets inside the image
+  uint32_t off_fwd, off_ent, off_pool, off_cls;  // byte offsets inside the image
   uint32_t nstates, nclasses, q0h, maxleaves, deadh, nullrow;
   const uint32_t* wlen;       // [nent] appended byte count / pool offset per back entry (wide form)
   const uint32_t* woff;
@@ -94,10 +101,11 @@ struct Lds {
   __device__ __forceinline__ uint32_t next(uint32_t h, uint32_t byte) const { return w(h + c4(byte)); }
   __device__ __forceinline__ uint8_t pb(uint32_t off) const { return base[pool + off]; }
 };
-#define E_LEAF4(e) ((e) & 0x3FFu)
-#define E_COPY(e) (((e) >> 10) & 1u)
-#define E_DLEN7(e) (((e) >> 11) & 0x7Fu)
-#define E_OFF14(e) ((e) >> 18)
+#define E_LEAF4(e) ((e) & 0x3FCu)
+#define E_COPY(e) (~(e) & 1u)
+#define E_DLEN7(e) ((e) >> 24)
+#define E_OFF13(e) (((e) >> 10) & 0x1FFFu)
+#define E_HASCONST(e) (((e) >> 23) & 1u)
 // WIDE = the program has back entries in the escaped wide form (long constants); programs without
 // them (all five workloads) run kernel instances in which the escape test does not exist at all.
 template <bool WIDE>
@@ -109,7 +117,7 @@ __device__ __forceinline__ uint32_t ent_dlen(uint32_t e, uint32_t addr, const Ld
 template <bool WIDE>
 __device__ __forceinline__ uint32_t ent_off(uint32_t e, uint32_t addr, const Lds& L, const DevTables& T) {
   if (WIDE) { if (__builtin_expect(E_DLEN7(e) == 127u, 0)) return T.woff[(addr - L.ent) >> 2]; }
-  return E_OFF14(e);
+  return E_OFF13(e);
 }
 
 __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) {
@@ -197,7 +205,7 @@ __global__ void k_sync(const uint8_t* __restrict__ in, uint64_t n, uint64_t seg,
     ++pos;
   }
   const uint32_t st = sid < M ? 0xFFFFu : state_of[sid];
-  if (st < 0xFFF0u) { seg_pos[k] = (uint64_t)k * seg + cnt + (M ? 1 : 0); seg_state[k] = (uint16_t)(st * C * 4); }
+  if (st < 0xFFF0u) { seg_pos[k] = (uint64_t)k * seg + cnt + (M ? 1 : 0); seg_state[k] = (uint16_t)(OFF_FWD + st * C * 4); }
   else { seg_pos[k] = UNSYNC; seg_state[k] = 0; atomicAdd(&flags->unsynced, 1u); }
 }
 
@@ -257,12 +265,13 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
   uint32_t h = seg_state[k];
   bool failed = false;
   while (pos < end && (pos & (PIECE - 1))) {
+    if ((pos & (HALF - 1)) == 0) chk[pos >> 5] = (uint16_t)h;
     uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { failed = true; break; }
     h = nh; ++pos;
   }
-  // 64 chained transitions over one piece held in registers
-  auto run_piece = [&](const uint32_t (&w)[16], uint32_t hh) {
+  // 64 chained transitions over one piece held in registers; `mid` = the state after the first 32
+  auto run_piece = [&](const uint32_t (&w)[16], uint32_t hh, uint32_t& mid) {
     uint32_t c[8], cn[8];
     static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.c4(BYTE_AT_DEP(w, i, hh)); });
     static_for<0, PIECE / 8>([&](auto gc) {
@@ -270,6 +279,7 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
       if constexpr (g + 1 < PIECE / 8)
         static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; cn[i] = L.c4(BYTE_AT_DEP(w, 8 * (g + 1) + i, hh)); });
       static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; hh = L.w(hh + c[i]) & 0xFFFFu; });
+      if constexpr (g == HALF / 8 - 1) mid = hh;
       if constexpr (g + 1 < PIECE / 8)
         static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = cn[i]; });
     });
@@ -286,41 +296,45 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
   };
   while (!failed && pos + PIECE <= end) {
     if ((pos & (8 * PIECE - 1)) == 0 && pos + 8 * PIECE <= end) {
-      // eight pieces per trip: their checkpoints leave as one aligned 16-byte store instead of eight
+      // eight pieces per trip: their sixteen checkpoints leave as two aligned 16-byte stores instead of
       // scattered 2-byte stores (each of which dirties a whole 64-byte sector)
-      uint32_t cw[4];
+      uint32_t cw[8];
       bool died = false;
       static_for<0, 4>([&](auto pc) {
         constexpr int k2 = decltype(pc)::value;
         if (!died) {
-          uint32_t wa[16], wb[16];
+          uint32_t wa[16], wb[16], mid = 0;
           load_pair(in, n, pos, wa, wb);   // one full 128-byte line per lane
-          cw[k2] = h;
           uint32_t h0 = h;
-          h = run_piece(wa, h);
+          h = run_piece(wa, h, mid);
+          cw[2 * k2] = h0 | (mid << 16);
           if (h == dead) { locate(h0); died = true; }
           else {
             pos += PIECE;
-            cw[k2] |= h << 16;
             h0 = h;
-            h = run_piece(wb, h);
+            h = run_piece(wb, h, mid);
+            cw[2 * k2 + 1] = h0 | (mid << 16);
             if (h == dead) { locate(h0); died = true; } else pos += PIECE;
           }
         }
       });
-      if (!died) *reinterpret_cast<uint4*>(chk + ((pos >> 6) - 8)) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+      if (!died) {
+        uint4* dst = reinterpret_cast<uint4*>(chk + ((pos >> 5) - 16));
+        dst[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+        dst[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+      }
       continue;
     }
-    chk[pos >> 6] = (uint16_t)h;
-    uint32_t w[16];
+    uint32_t w[16], mid = 0;
     load_piece(in, n, pos, w);
     const uint32_t h0 = h;
-    h = run_piece(w, h);
+    h = run_piece(w, h, mid);
     if (h == dead) { locate(h0); break; }
+    *reinterpret_cast<uint32_t*>(chk + (pos >> 5)) = h0 | (mid << 16);
     pos += PIECE;
   }
   while (!failed && pos < end) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
+    if ((pos & (HALF - 1)) == 0) chk[pos >> 5] = (uint16_t)h;
     uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { failed = true; break; }
     h = nh; ++pos;
@@ -328,7 +342,7 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
   if (failed) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
   if (last) {
     flags->end_state = h;
-    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)h;
+    if ((n & (HALF - 1)) == 0) chk[n >> 5] = (uint16_t)h;
   }
 }
 
@@ -340,14 +354,14 @@ __global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head
   if (blockIdx.x || threadIdx.x) return;
   const uint32_t dead = T.deadh;
   for (uint64_t pos = 0; pos < head_len; ++pos) {
-    if ((pos & (PIECE - 1)) == 0) chk[pos >> 6] = (uint16_t)h;
+    if ((pos & (HALF - 1)) == 0) chk[pos >> 5] = (uint16_t)h;
     uint32_t nh = L.next(h, in[pos]) & 0xFFFFu;
     if (nh == dead) { atomicMin(&flags->fail_pos, (unsigned long long)pos); return; }
     h = nh;
   }
   if (head_len == n) {
     flags->end_state = h;
-    if ((n & (PIECE - 1)) == 0) chk[n >> 6] = (uint16_t)h;
+    if ((n & (HALF - 1)) == 0) chk[n >> 5] = (uint16_t)h;
   }
 }
 
@@ -368,6 +382,10 @@ constexpr int BOW = PIECE / 2;
 __device__ __forceinline__ void bo_set(uint32_t (&bo)[BOW], int t, uint32_t v) {
   bo[t >> 1] = (t & 1) ? ((bo[t >> 1] & 0xFFFFu) | (v << 16)) : ((bo[t >> 1] & 0xFFFF0000u) | v);
 }
+// piece_forward2 / piece_sweep2: the hand-scheduled two-chain sequences (generated text, see gen_sweeps.py)
+#include "kx_sweeps.inc"
+// one chain, scheduled by the compiler: k_backlen keeps two pieces of input in registers and has no room
+// for the two-chain sequence's 62 simultaneously live registers
 __device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t h, const Lds& L, uint32_t (&bo)[BOW]) {
   // byte-class lookups do not depend on the state, so they are prefetched one group of 8 ahead of
   // the dependent fwd[] chain — and no further (all 64 at once would cost 64 VGPRs)
@@ -415,6 +433,24 @@ __device__ __forceinline__ uint32_t walk_len(const uint32_t (&bo)[BOW], uint32_t
   });
   return sum;
 }
+// The same walk, also reporting where it stood in the middle of the piece (leaf entering step 31 and
+// the bytes appended by steps 63..32): k_emit starts its second dependency chain there.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t walk_len_mid(const uint32_t (&bo)[BOW], uint32_t& leaf, uint32_t& leaf_mid, uint32_t& sum_hi,
+                                                 const Lds& L, const DevTables& T) {
+  uint32_t sum = 0;
+  static_for<0, PIECE>([&](auto ic) {
+    constexpr int t = PIECE - 1 - decltype(ic)::value;
+    const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+    const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
+    if constexpr (t == HALF) { leaf_mid = leaf; sum_hi = sum; }
+  });
+  return sum;
+}
+// piece record word: end leaf | leaf in the middle << 8 | min(bytes of the upper half, 0xFFFF) << 16
+__device__ __forceinline__ uint32_t rec_word(uint32_t leaf_end, uint32_t leaf_mid4, uint32_t sum_hi) {
+  return leaf_end | ((leaf_mid4 >> 2) << 8) | ((sum_hi < 0xFFFFu ? sum_hi : 0xFFFFu) << 16);
+}
 
 template <int MAXC, bool WIDE>
 __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
@@ -424,14 +460,14 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
                           uint16_t* __restrict__ merge_piece, uint32_t* __restrict__ ctot, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
-  // per-lane staging behind the table image: 8 piece records (64 B) and 8 checkpoints (16 B), so that
-  // both move as whole aligned 64/16-byte lines instead of scattered 1-4 byte accesses
+  // per-lane staging behind the table image: 8 piece records (64 B) and 8 piece-start checkpoints (16 B), so
+  // that both move as whole aligned lines instead of scattered 1-4 byte accesses
   uint4* lrec = reinterpret_cast<uint4*>(smem + ((T.packed_words + 3) & ~3u)) + (size_t)threadIdx.x * 5;
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
-  const uint32_t qe = (bend == n ? flags->end_state : chk[bend >> 6]) / (T.nclasses * 4);
+  const uint32_t qe = ((bend == n ? flags->end_state : chk[bend >> 5]) - OFF_FWD) / (T.nclasses * 4);
   // candidate 0 lives in registers (after merging it is the only one left); candidates 1.. in private memory
   uint16_t cl[MAXC]; uint32_t clen[MAXC]; uint32_t pre[MAXC];   // cl = leaf·4
   uint32_t nc, nact, leaf0, len0 = 0, pre0 = 0;
@@ -458,19 +494,25 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
         const uint64_t pstart = bstart + (uint64_t)p * PIECE;
         const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
         uint32_t bo[BOW];
-        // checkpoints arrive 8 at a time (k_forward stores them that way); the piece index is 8-aligned
+        // checkpoints arrive 16 at a time (k_forward stores them that way); the piece index is 8-aligned
         // with the block, so group (p | 7) is fetched when the sweep first enters it
-        uint32_t hstart;
+        uint32_t hA;
         if (batch) {
-          if ((p & 7) == 7 || p == npieces - 1) lrec[4] = *reinterpret_cast<const uint4*>(chk + ((piece0 + p) & ~7ull));
-          hstart = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
-        } else hstart = chk[piece0 + p];
-        piece_forward(w, hstart, L, bo);
+          if ((p & 7) == 7 || p == npieces - 1) {
+            const uint4* src = reinterpret_cast<const uint4*>(chk + 2 * ((piece0 + p) & ~7ull));
+            const uint4 c0 = src[0], c1 = src[1];   // (start, middle) handles of 8 pieces: keep the starts
+            lrec[4] = make_uint4((c0.x & 0xFFFFu) | (c0.y << 16), (c0.z & 0xFFFFu) | (c0.w << 16),
+                                 (c1.x & 0xFFFFu) | (c1.y << 16), (c1.z & 0xFFFFu) | (c1.w << 16));
+          }
+          hA = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
+        } else hA = chk[2 * (piece0 + p)];
+        piece_forward(w, hA, L, bo);
         mask_tail(bo, plen, T.nullrow);
         if (nact == 1) {
           const uint32_t leaf_end = leaf0 >> 2;
-          len0 += walk_len<WIDE>(bo, leaf0, L, T);
-          const PieceRec rec{(int32_t)(len0 - pre0), leaf_end};
+          uint32_t lmid = 0, shi = 0;
+          len0 += walk_len_mid<WIDE>(bo, leaf0, lmid, shi, L, T);
+          const PieceRec rec{(int32_t)(len0 - pre0), rec_word(leaf_end, lmid, shi)};
           if (batch) {
             reinterpret_cast<PieceRec*>(lrec)[p & 7] = rec;
             if ((p & 7) == 0) {   // records p..p+7 are complete (or belong to the unresolved tail: k_fixtail rewrites those)
@@ -632,88 +674,120 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
     uint32_t w[16], bo[BOW];
     load_piece(in, n, pstart, w);
-    piece_forward(w, chk[pstart >> 6], L, bo);
+    const uint32_t hh = reinterpret_cast<const uint32_t*>(chk)[pstart >> 6];
+    piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
     mask_tail(bo, plen, T.nullrow);
     const uint32_t leaf_end = leaf >> 2;
-    suffix += walk_len<WIDE>(bo, leaf, L, T);
-    prec[piece0 + p] = PieceRec{base + (int32_t)suffix, leaf_end};
+    uint32_t lmid = 0, shi = 0;
+    suffix += walk_len_mid<WIDE>(bo, leaf, lmid, shi, L, T);
+    prec[piece0 + p] = PieceRec{base + (int32_t)suffix, rec_word(leaf_end, lmid, shi)};
   }
 }
 
 // ------------------------------------------------------------------------------- k_emit
 // One lane = one 64-byte piece; one wave-iteration = 64 consecutive pieces = 4 KiB of contiguous
-// input and a contiguous stretch of output.  Every lane re-derives its piece, walks it backward
-// from its resolved end leaf, then the wave assembles the output in an LDS staging buffer —
-// copied input bytes by their owning lane, constants by a wave-wide job list (one lane per
-// constant, so that the cost does not depend on which lanes happen to sit on a constant) — and
-// flushes it with aligned 16-byte stores.  Persistent workgroups: tables are staged once per CU.
+// input and a contiguous stretch of output, assembled in an LDS staging buffer and flushed with
+// aligned 16-byte stores.  Every lane re-derives the back rows of its piece, then walks them
+// backward from its resolved end leaf *and places the output in the same sweep*: the piece's output
+// range is known beforehand from the piece records (start = its own record, end = the next piece's
+// start), so the write cursor simply runs down from the end.  Copied input bytes are stored by
+// the walking lane; constants are noted as (entry, cursor) pairs in lane-private job slots and
+// copied after the sweep.  Persistent workgroups: tables are staged once per CU.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// One step of the sweep (program without wide entries; piece_sweep2 in kx_sweeps.inc runs two chains
+// of them per lane): 6 VALU + 1 LDS read + 1 LDS write,
+//   a = row(t) + leaf;  e = lds[a];  leaf = e & 0x3FC;  o -= e.byte3;
+//   lds8[o | e<<31] = input byte t          (a step that copies nothing addresses out of range: dropped)
+//   if (e.bit23) { job slot <- o<<16 | a; slot += stride (saturating at the sink) }
+// The step in plain C++ for the other program shapes (one chain).  CONSTS: 0 = note a job, 1 = copy the
+// constant in place (short constants, or the second attempt of a lane whose job slots overflowed).
+template <int T_, bool WIDE, int CONSTS>
+__device__ __forceinline__ void emit_step_gen(const uint32_t (&bo)[BOW], const uint32_t (&w)[16], uint32_t& leaf, uint32_t& o,
+                                              uint32_t& jp, uint32_t js, uint32_t jl, const Lds& L, const DevTables& T) {
+  const uint32_t a = BO_GET_DEP(bo, T_, leaf) + leaf;
+  const uint32_t e = L.w(a);
+  leaf = E_LEAF4(e);
+  const uint32_t dl = ent_dlen<WIDE>(e, a, L, T), cp = E_COPY(e);
+  o -= dl;
+  uint8_t* stg0 = const_cast<uint8_t*>(L.base);
+  if (cp) stg0[o] = (uint8_t)BYTE_AT_DEP(w, T_, e);
+  if (E_HASCONST(e)) {
+    if constexpr (CONSTS == 0) {
+      *reinterpret_cast<uint32_t*>(stg0 + jp) = (o << 16) | a;
+      jp = jp + js < jl ? jp + js : jl;
+    } else {
+      const uint32_t cl = dl - cp, src = ent_off<WIDE>(e, a, L, T);
+      for (uint32_t i = 0; i < cl; ++i) stg0[o + cp + i] = L.pb(src + i);
+    }
+  }
+}
 
 template <int WAVES, int MODE>   // MODE 0: plain; 1: wide back entries; 2: every constant ≤ EMIT_INLINE bytes → written in place
 __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
-                                                     const unsigned long long* __restrict__ off, uint32_t init_shift,
+                                                     const unsigned long long* __restrict__ off, const Flags* __restrict__ flags,
+                                                     uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
   constexpr bool WIDE = MODE == 1;
-  constexpr bool INL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables(T, smem);
+  // the sweeps address LDS absolutely (16-bit row offsets, staging cursors): the image must sit at LDS address 0
+  if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* stg = (uint8_t*)(smem + ((T.packed_words + 3) & ~3u)) + (size_t)wave * EMIT_WAVE_LDS;
-  uint32_t* jobs = (uint32_t*)(stg + EMIT_STG + 16);
+  const uint32_t stga = ((T.packed_words + 3) & ~3u) * 4 + wave * EMIT_WAVE_LDS;   // LDS address of this wave's staging area
+  uint8_t* stg = (uint8_t*)smem + stga;
+  const uint32_t jarea = stga + EMIT_STG + 16;
   if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pb(T.init_off[init_leaf] + threadIdx.x);
   if (is_first && blockIdx.x == 0 && init_shift > blockDim.x)
     for (uint32_t i = blockDim.x + threadIdx.x; i < init_shift; i += blockDim.x) out[i] = L.pb(T.init_off[init_leaf] + i);
   const uint64_t nwi = (npieces_total + 63) / 64;
+  const uint64_t oend_all = (uint64_t)init_shift + flags->total_len;
+  auto piece_ostart = [&](uint64_t pc, const PieceRec& r) {
+    const uint64_t m = pc * PIECE / blk;
+    return (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - r.cum);
+  };
   for (uint64_t it = (uint64_t)blockIdx.x * WAVES + wave; it < nwi; it += (uint64_t)gridDim.x * WAVES) {
     const uint64_t piece = it * 64 + lane;
     const bool valid = piece < npieces_total;
     const uint64_t pstart = piece * PIECE;
     const int plen = valid ? (int)(n - pstart < PIECE ? n - pstart : PIECE) : 0;
     uint32_t w[16], bo[BOW];
-    uint32_t olen = 0, nj = 0;
-    uint64_t ostart = 0;
     load_piece(in, n, valid ? pstart : n, w);
-    piece_forward(w, valid ? chk[piece] : T.deadh, L, bo);
-    mask_tail(bo, plen, T.nullrow);
     const PieceRec rec = valid ? prec[piece] : PieceRec{0, 0};
-    {
-      uint32_t leaf = rec.leaf * 4;
-      static_for<0, PIECE>([&](auto ic) {
-        constexpr int t = PIECE - 1 - decltype(ic)::value;
-        const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
-        const uint32_t e = L.w(a);
-        bo_set(bo, t, a);
-        const uint32_t dl = ent_dlen<WIDE>(e, a, L, T);
-        olen += dl;
-        nj += !INL && dl > E_COPY(e) ? 1u : 0u;
-        leaf = E_LEAF4(e);
-        tie(leaf, olen); tie(leaf, nj);
-      });
+    uint64_t ostart = valid ? piece_ostart(piece, rec) : 0, oend;
+    {   // end of the piece's output = start of the next piece's
+      const uint32_t lo = __shfl_down((uint32_t)ostart, 1), hi = __shfl_down((uint32_t)(ostart >> 32), 1);
+      oend = ((uint64_t)hi << 32) | lo;
+      if (valid && (lane == 63 || piece + 1 == npieces_total))
+        oend = piece + 1 == npieces_total ? oend_all : piece_ostart(piece + 1, prec[piece + 1]);
+      if (!valid) oend = ostart;
     }
-    if (valid) {
-      const uint64_t m = pstart / blk;
-      ostart = (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - rec.cum);
-    }
-    // inclusive prefix of the job counts over the wave
-    uint32_t pj = nj;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t x = __shfl_up(pj, d); if ((int)lane >= d) pj += x; }
+    const uint32_t hh = valid ? reinterpret_cast<const uint32_t*>(chk)[piece] : T.deadh * 0x10001u;
+    piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
+    mask_tail(bo, plen, T.nullrow);
+    const uint32_t leaf_end4 = (rec.leaf & 0xFFu) * 4, leaf_mid4 = ((rec.leaf >> 8) & 0xFFu) * 4, len_hi = rec.leaf >> 16;
     const unsigned long long vmask = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vmask);
     uint32_t first = 0;
     while (first < nvalid) {
       const uint64_t gs = __shfl(ostart, first);
       const uint64_t abase = gs & ~15ull;
-      const uint32_t pj_before = first ? __shfl(pj, first - 1) : 0u;
-      const bool fits = valid && lane >= first && (ostart + olen - abase) <= (uint64_t)EMIT_STG && (pj - pj_before) <= (uint32_t)EMIT_JCAP;
+      const bool fits = valid && lane >= first && (oend - abase) <= (uint64_t)EMIT_STG && len_hi != 0xFFFFu;
       const unsigned long long fm = __ballot(fits) >> first;
       const uint32_t cnt = fm == ~0ull ? 64u - first : (uint32_t)__builtin_ctzll(~fm);   // leading run of fitting lanes
       if (cnt == 0) {
         // a single piece larger than the staging area: its lane writes straight to global memory
         if (lane == first) {
+          uint32_t leaf = leaf_end4;
+          static_for<0, PIECE>([&](auto ic) {
+            constexpr int t = PIECE - 1 - decltype(ic)::value;
+            const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
+            bo_set(bo, t, a);
+            leaf = E_LEAF4(L.w(a));
+          });
           uint64_t o = ostart;
           static_for<0, PIECE>([&](auto ic) {
             constexpr int t = decltype(ic)::value;
@@ -729,50 +803,56 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       }
       const uint32_t lastl = first + cnt - 1;
       const bool active = lane >= first && lane <= lastl;
-      launder(w); launder(bo);
-      // phase 1: copied bytes into staging, constants into the job list
+      const uint32_t oe = stga + (uint32_t)(oend - abase);   // LDS address one past the piece's staged output
+      // job slots: EMIT_JOBS/4 four-byte slots dealt out evenly to the round's lanes, slot k of a lane at
+      // jfirst + k*stride (bank-conflict free); the last slot is a sink that marks overflow
+      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((EMIT_JOBS / 4) / cnt - 1) * js;
+      uint32_t jp = jfirst;
+      // sweep: copied bytes into staging, constants into the lane's job slots (or in place)
       if (active) {
-        uint32_t o = (uint32_t)(ostart - abase);
-        uint32_t ji = (pj - nj) - pj_before;
-        // table words of 8 steps are fetched together (they are independent of each other); the offset
-        // chain then runs on registers
-        static_for<0, PIECE / 8>([&](auto gc) {
-          constexpr int g = decltype(gc)::value;
-          uint32_t a8[8], e8[8];
-          static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; a8[i] = BO_GET_DEP(bo, 8 * g + i, o); e8[i] = L.w(a8[i]); });
-          static_for<0, 8>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int t = 8 * g + i;
-            const uint32_t e = e8[i];
-            const uint32_t cp = E_COPY(e), dl = ent_dlen<WIDE>(e, a8[i], L, T);
-            if (cp) stg[o] = (uint8_t)BYTE_AT_DEP(w, t, e);
-            if (dl > cp) {
-              const uint32_t cl = dl - cp, src = ent_off<WIDE>(e, a8[i], L, T);
-              if (INL) {   // a program whose constants are all one or two bytes: cheaper in place than as jobs
-                stg[o + cp] = L.pb(src);
-                if (cl == 2) stg[o + cp + 1] = L.pb(src + 1);
-              } else { jobs[2 * ji] = (o + cp) | (cl << 16); jobs[2 * ji + 1] = src; ++ji; }
-            }
-            o += dl;
+        if constexpr (MODE == 0) {
+          piece_sweep2(bo, w, leaf_end4, oe, leaf_mid4, oe - len_hi, jp, js, jlast);
+        } else {
+          uint32_t leaf = leaf_end4, o = oe;
+          static_for<0, PIECE>([&](auto ic) {
+            constexpr int t = PIECE - 1 - decltype(ic)::value;
+            emit_step_gen<t, WIDE, MODE == 2 ? 1 : 0>(bo, w, leaf, o, jp, js, jlast, L, T);
           });
-        });
-      }
-      wave_lds_fence();
-      // phase 2: one lane per constant
-      const uint32_t njobs = __shfl(pj, lastl) - pj_before;
-      for (uint32_t j = lane; j < njobs; j += 64) {
-        const uint32_t a = jobs[2 * j], src = jobs[2 * j + 1];
-        const uint32_t d = a & 0xFFFFu, l = a >> 16;
-        uint32_t i = 0;
-        for (; i + 4 <= l; i += 4) {
-          const uint8_t b0 = L.pb(src + i), b1 = L.pb(src + i + 1), b2 = L.pb(src + i + 2), b3 = L.pb(src + i + 3);
-          stg[d + i] = b0; stg[d + i + 1] = b1; stg[d + i + 2] = b2; stg[d + i + 3] = b3;
         }
-        for (; i < l; ++i) stg[d + i] = L.pb(src + i);
+      }
+      if constexpr (MODE != 2) {
+        // a lane that ran out of job slots sweeps once more, copying its constants in place
+        const bool ovf = active && jp == jlast;
+        if (__any(ovf)) {
+          if (ovf) {
+            uint32_t leaf = leaf_end4, o = oe, jq = 0;
+            static_for<0, PIECE>([&](auto ic) {
+              constexpr int t = PIECE - 1 - decltype(ic)::value;
+              emit_step_gen<t, WIDE, 1>(bo, w, leaf, o, jq, 0u, 0u, L, T);
+            });
+            jp = jfirst;
+          }
+        }
+        wave_lds_fence();
+        // constants: every lane copies the ones its own piece noted
+        const uint32_t nj = active ? (jp - jfirst) / js : 0u;
+        for (uint32_t k = 0; __any(k < nj); ++k) {
+          if (k < nj) {
+            const uint32_t jb = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jfirst + k * js);
+            const uint32_t a = jb & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
+            const uint32_t d = stga + (((jb >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
+            uint8_t* dst = (uint8_t*)smem + d;
+            const uint8_t* sp = L.base + L.pool + src;
+            uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
+            for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
+            if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
+            if (l & 1) dst[i] = sp[i];
+          }
+        }
       }
       wave_lds_fence();
       // flush [gs, ge): partial head and tail windows bytewise, everything between as aligned 16 B
-      const uint64_t ge = __shfl(ostart + olen, lastl);
+      const uint64_t ge = __shfl(oend, lastl);
       const uint64_t fs = (gs + 15) & ~15ull, fe = ge & ~15ull;
       if (fs >= fe) {
         for (uint64_t x = gs + lane; x < ge; x += 64) out[x] = stg[x - abase];
@@ -848,7 +928,7 @@ struct kx_shard {
   unsigned long long *off, *wsum, *woff;
   // control state mirrored on the host
   Flags hflags{}; uint64_t head_len = 0; bool have_end = false; uint64_t out_len = 0; uint32_t init_shift = 0, init_leaf = 0;
-  uint32_t endId() const { return hflags.end_state / (st->nclasses * 4); }
+  uint32_t endId() const { return (hflags.end_state - OFF_FWD) / (st->nclasses * 4); }
   kx_stats stats{};
 };
 
@@ -881,18 +961,19 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t* sync_next = (const uint32_t*)c; c += (size_t)nsync * C * 4;
   const uint32_t* sync_state = (const uint32_t*)c; c += (size_t)nsync * 4;
   if (c > end) return setErr(KX_E_BLOB, "truncated stage body");
-  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C * 4 > 0xFFF0)
+  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C * 4 + 512 > 0xFFF0)
     return setErr(KX_E_BLOB, "program outside engine limits (states x classes / leaves)");
 
   S.nstates = nstates; S.nclasses = C; S.q0 = q0; S.maxleaves = Lm;
   // ragged back rows: row b keeps entries up to its last live leaf.  Compact entry (see DevTables);
-  // entries that do not fit (≥127 appended bytes, pool offset ≥ 16 KiB) escape to the wide side tables.
+  // entries that do not fit (≥127 appended bytes, pool offset ≥ 8 KiB) escape to the wide side tables.
   std::vector<uint32_t> rowoff(nback), ent, wlen, woff;
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
-    const bool wide = dlen >= 127 || poff >= (1u << 14);
+    const bool wide = dlen >= 127 || poff >= (1u << 13);
     if (wide) S.wide = true;
     if (dlen - copy > (uint32_t)EMIT_INLINE) S.short_consts = false;
-    ent.push_back((parent * 4) | (copy << 10) | ((wide ? 127u : dlen) << 11) | ((wide ? 0u : poff) << 18));
+    ent.push_back((copy ? 0u : 1u) | (parent << 2) | ((wide ? 0u : poff) << 10) | (dlen > copy ? 1u << 23 : 0u) |
+                  ((wide ? 127u : dlen) << 24));
     wlen.push_back(dlen); woff.push_back(poff);
   };
   for (uint32_t b = 0; b < nback; ++b) {
@@ -913,29 +994,29 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t nullrow_idx = (uint32_t)ent.size();
   for (uint32_t j = 0; j < Lm; ++j) pushEnt(j, 0, 0, 0);
   for (uint32_t j = 0; j < Lm; ++j) pushEnt(0, 0, 0, 0);
-  const uint32_t fwd_bytes = (nstates + 1) * C * 4;
-  const uint32_t off_ent = fwd_bytes;
+  // LDS image: cls4 (512 B, at LDS address 0: the hand-scheduled sweeps read it with no base) | fwd | ent | pool
+  const uint32_t off_fwd = OFF_FWD, fwd_bytes = (nstates + 1) * C * 4;
+  const uint32_t off_ent = off_fwd + fwd_bytes;
   if ((size_t)off_ent + ent.size() * 4 > 65532)
     return setErr(KX_E_BLOB, "program tables exceed the engine's 16-bit LDS addressing (states x classes + path table > 64 KiB)");
-  const uint32_t deadh = nstates * C * 4;              // handle of the absorbing "no transition" state
-  std::vector<uint32_t> fwd((size_t)(nstates + 1) * C);
-  for (uint32_t q = 0; q < nstates; ++q)
-    for (uint32_t k = 0; k < C; ++k) {
-      uint16_t d = delta[(size_t)q * C + k];
-      fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? deadh
-                               : ((uint32_t)d * C * 4 | ((off_ent + rowoff[pback[(size_t)q * C + k]] * 4) << 16));
-    }
-  for (uint32_t k = 0; k < C; ++k) fwd[(size_t)nstates * C + k] = deadh;
-
-  // LDS image: fwd | ent | pool | cls4
-  std::vector<uint32_t> packed(fwd);
+  const uint32_t deadh = off_fwd + nstates * C * 4;    // handle of the absorbing "no transition" state
+  std::vector<uint32_t> packed(128 + (size_t)(nstates + 1) * C);
+  for (int b = 0; b < 256; ++b) ((uint16_t*)packed.data())[b] = (uint16_t)(cls[b] * 4);
+  {
+    uint32_t* fwd = packed.data() + 128;
+    for (uint32_t q = 0; q < nstates; ++q)
+      for (uint32_t k = 0; k < C; ++k) {
+        uint16_t d = delta[(size_t)q * C + k];
+        fwd[(size_t)q * C + k] = d == KXP_NO_STATE ? deadh
+                                 : ((off_fwd + (uint32_t)d * C * 4) | ((off_ent + rowoff[pback[(size_t)q * C + k]] * 4) << 16));
+      }
+    for (uint32_t k = 0; k < C; ++k) fwd[(size_t)nstates * C + k] = deadh;
+  }
   packed.insert(packed.end(), ent.begin(), ent.end());
   const uint32_t off_pool = (uint32_t)packed.size() * 4;
   packed.resize(packed.size() + pad4(pcpl + 4) / 4, 0);
   memcpy((char*)packed.data() + off_pool, pcpool, pcpl);
-  const uint32_t off_cls = (uint32_t)packed.size() * 4;
-  packed.resize(packed.size() + 128);
-  for (int b = 0; b < 256; ++b) ((uint16_t*)((char*)packed.data() + off_cls))[b] = (uint16_t)(cls[b] * 4);
+  const uint32_t off_cls = 0;
   S.lds_bytes = packed.size() * 4;
   if (S.lds_bytes > 150 * 1024) return setErr(KX_E_BLOB, "program tables exceed the LDS budget (150 KiB)");
   const uint32_t nullrow = off_ent + nullrow_idx * 4;
@@ -991,7 +1072,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   T.packed = (const uint32_t*)(d + o_packed); T.packed_words = (uint32_t)packed.size();
   T.off_ent = off_ent; T.off_pool = off_pool; T.off_cls = off_cls;
   T.wlen = (const uint32_t*)(d + o_wl); T.woff = (const uint32_t*)(d + o_wo);
-T.nstates = nstates; T.nclasses = C; T.q0h = q0 * C * 4; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
+T.nstates = nstates; T.nclasses = C; T.off_fwd = off_fwd; T.q0h = off_fwd + q0 * C * 4; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
   T.cls = (const uint8_t*)(d + o_cls); T.nleaves = (const uint8_t*)(d + o_nl); T.fin_leaf = (const uint8_t*)(d + o_fl);
   T.sync16 = (const uint16_t*)(d + o_sn); T.nsync = nsync; T.sync_multi = nmulti; T.sync_words = (uint32_t)(sync_bytes / 4);
   T.init_off = (const uint32_t*)(d + o_io); T.init_len = (const uint32_t*)(d + o_il);
@@ -1039,6 +1120,7 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   const size_t tab = (lds + 15) & ~(size_t)15;
   p->emit_waves = tab + 16 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 16 : tab + 12 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 12
                   : tab + 8 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 8 : 4;
+  if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12 || v == 16) && v < p->emit_waves) p->emit_waves = v; }
   if (tab + 4 * (size_t)EMIT_WAVE_LDS > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
   int rc = setLds((const void*)k_forward, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_head, lds); if (rc) { kx_free(p); return rc; }
@@ -1099,14 +1181,14 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   s->ngroups = (s->nblk + bt - 1) / bt;
   // workspace layout
   Arena& A = p->arena;
-  size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / PIECE + 16) * 2 + sizeof(Flags) +
+  size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / HALF + 32) * 2 + sizeof(Flags) +
                 (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8 + 2 + 4) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
                 (n / PIECE + 16) * 8 + 256 * 32;
   int rc = A.reserve(need);
   if (rc) { delete s; return rc; }
   A.reset();
   s->seg_pos = A.take<uint64_t>(s->nseg); s->seg_state = A.take<uint16_t>(s->nseg);
-  s->chk = A.take<uint16_t>(n / PIECE + 16); s->flags = A.take<Flags>(1);
+  s->chk = A.take<uint16_t>(n / HALF + 32); s->flags = A.take<Flags>(1);
   s->bs_start = A.take<uint8_t>((size_t)s->nblk * s->Lc); s->bs_len = A.take<uint32_t>((size_t)s->nblk * s->Lc);
   s->bs_merged = A.take<uint8_t>(s->nblk); s->bs_mstart = A.take<uint8_t>(s->nblk); s->E = A.take<uint8_t>(s->nblk);
   s->len = A.take<uint32_t>(s->nblk); s->off = A.take<unsigned long long>(s->nblk);
@@ -1142,7 +1224,7 @@ int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
   kx_program* p = s->prog; Stage& S = *s->st;
   const uint32_t bt = p->cfg.block_threads;
   const bool timing = p->cfg.collect_timing;
-  Flags init{}; init.fail_pos = NOFAIL; init.end_state = S.q0 * S.nclasses * 4; init.first_merged = 0xFFFFFFFFu;
+  Flags init{}; init.fail_pos = NOFAIL; init.end_state = OFF_FWD + S.q0 * S.nclasses * 4; init.first_merged = 0xFFFFFFFFu;
   HIPCHECK(hipMemcpyAsync(s->flags, &init, sizeof(Flags), hipMemcpyHostToDevice, s->stream));
   if (s->n == 0) {  // nothing to scan: the state entering byte 0 is also the end state
     s->hflags = init; s->head_len = 0; s->have_end = s->is_first != 0;
@@ -1190,14 +1272,14 @@ int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out)
     const bool timing = p->cfg.collect_timing;
     if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
     hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len,
-                       incoming_state * S.nclasses * 4, s->chk, s->flags, S.T);
+                       OFF_FWD + incoming_state * S.nclasses * 4, s->chk, s->flags, S.T);
     if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
     HIPCHECK(hipGetLastError());
     int rc = readFlags(s);
     if (rc) return rc;
     if (timing) s->stats.kernel_ms[KX_K_HEAD] = evMs(p->ev[0], p->ev[1]);
   } else if (!s->is_first && s->n == 0) {
-    s->hflags.end_state = incoming_state * S.nclasses * 4;
+    s->hflags.end_state = OFF_FWD + incoming_state * S.nclasses * 4;
   }
   s->have_end = true;
   if (s->is_last && s->hflags.fail_pos == NOFAIL && S.h_fin_leaf[s->endId()] == KXP_NO_LEAF)
@@ -1310,7 +1392,7 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
-                     s->prec, s->ctot, s->off, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+                     s->prec, s->ctot, s->off, s->flags, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
   const int mode = S.wide ? 1 : S.short_consts ? 2 : 0;
   if (mode == 1) { if (W == 16) KX_LAUNCH_EMIT(16, 1); else if (W == 12) KX_LAUNCH_EMIT(12, 1); else if (W == 8) KX_LAUNCH_EMIT(8, 1); else KX_LAUNCH_EMIT(4, 1); }
   else if (mode == 2) { if (W == 16) KX_LAUNCH_EMIT(16, 2); else if (W == 12) KX_LAUNCH_EMIT(12, 2); else if (W == 8) KX_LAUNCH_EMIT(8, 2); else KX_LAUNCH_EMIT(4, 2); }

@@ -8,7 +8,7 @@ before doing the bookkeeping of the current step.
 
   piece_forward2(w, hA, hB, himask) -> bo[32]
       forward re-derivation of the back rows: chain A = bytes 0..31 from state handle hA,
-      chain B = bytes 32..63 from hB.  Per byte and chain: 1 SDWA shift (class address), 1 ds_read_u16
+      chain B = bytes 32..63 from hB.  Per byte and chain: 1 SDWA byte extract (class address), 1 ds_read_u8
       (class*4), 1 SDWA add on the chain (next fwd address = e.lo16 + class*4), 1 ds_read_b32, 1 op
       packing the row offset (e.hi16) into bo.  The class table sits at LDS address 0.
 
@@ -30,8 +30,8 @@ def fwd2():
     # rotating registers: e{A,B}{0,1} fwd words, c{A,B}{0,1,2} classes (prefetch distance 2), x{A,B} class addresses
     def cls_issue(ch, t, slot):
         wi, by = t >> 2, t & 3
-        ap("v_lshlrev_b32_sdwa %%[x%s], 1, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (ch, wi, SD, by))
-        ap("ds_read_u16 %%[c%s%d], %%[x%s]" % (ch, slot, ch))
+        ap("v_lshlrev_b32_sdwa %%[x%s], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (ch, wi, SD, by))
+        ap("ds_read_u8 %%[c%s%d], %%[x%s]" % (ch, slot, ch))
     base = {"A": 0, "B": 32}
     for d in (0, 1):
         for ch in "AB":

@@ -56,7 +56,7 @@ int setErr(int code, const std::string& m) { g_err = m; return code; }
 
 constexpr int PIECE = 64;                 // bytes per lane-step of the backward kernels (one piece record each)
 constexpr int HALF = 32;                  // bytes between state checkpoints (two dependency chains per piece)
-constexpr uint32_t OFF_FWD = 512;         // the table image starts with the 512-byte class table; state rows follow
+constexpr uint32_t OFF_FWD = 256;         // the table image starts with the 256-byte class table; state rows follow
 constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
 constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
@@ -69,7 +69,8 @@ constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JOBS;
 // addressed by *byte offsets* that are stored pre-scaled inside the tables themselves, so that a
 // lookup is one add + one ds_read:
 //   state handle h   = byte offset of the state's row in the image     (h = off_fwd + state·C·4)
-//   cls4[byte]       = class·4                                        (u16 table)
+//   cls4[byte]       = class·4 (u8 table at LDS address 0; programs with more than 64 byte classes
+//                      store the class index and shift: DevTables::cshift)
 //   e = fwd[h + cls4[b]] :  low 16 = next handle, high 16 = byte offset of the transition's back row
 //   back entry x = ent[row + leaf·4] :
 //     bit 0 "no input byte copied" | bits 2-9 leaf' (so x & 0x3FC = leaf'·4) | bits 10-22 pool offset |
@@ -82,7 +83,7 @@ struct DevTables {
   const uint32_t* packed;     // [cls4 | fwd | ent | pool] image
   uint32_t packed_words;
   uint32_t off_fwd, off_ent, off_pool, off_cls;  // byte offsets inside the image
-  uint32_t nstates, nclasses, q0h, maxleaves, deadh, nullrow;
+  uint32_t nstates, nclasses, q0h, maxleaves, deadh, nullrow, cshift;
   const uint32_t* wlen;       // [nent] appended byte count / pool offset per back entry (wide form)
   const uint32_t* woff;
   const uint8_t* cls;         // global copy for kernels that do not stage the big image
@@ -95,9 +96,10 @@ struct DevTables {
 };
 
 struct Lds {
-  const uint8_t* base; uint32_t cls, pool, ent;
+  const uint8_t* base; uint32_t cls, pool, ent, csh;
   __device__ __forceinline__ uint32_t w(uint32_t off) const { return *reinterpret_cast<const uint32_t*>(base + off); }
-  __device__ __forceinline__ uint32_t c4(uint32_t byte) const { return *reinterpret_cast<const uint16_t*>(base + cls + 2 * byte); }
+  // one byte per input symbol: ASCII text then never collides in an LDS bank (a u16 table aliases b and b+64)
+  __device__ __forceinline__ uint32_t c4(uint32_t byte) const { return (uint32_t)base[cls + byte] << csh; }
   __device__ __forceinline__ uint32_t next(uint32_t h, uint32_t byte) const { return w(h + c4(byte)); }
   __device__ __forceinline__ uint8_t pb(uint32_t off) const { return base[pool + off]; }
 };
@@ -120,11 +122,15 @@ __device__ __forceinline__ uint32_t ent_off(uint32_t e, uint32_t addr, const Lds
   return E_OFF13(e);
 }
 
+// GENERAL = kernel instance for programs with wide back entries or more than 64 byte classes; the
+// common instances know at compile time that neither exists (class shift 0, no escape tests).
+template <bool GENERAL>
 __device__ __forceinline__ Lds stage_tables(const DevTables& T, uint32_t* smem) {
   for (uint32_t i = threadIdx.x; i < T.packed_words; i += blockDim.x) smem[i] = T.packed[i];
   __syncthreads();
   Lds L;
   L.base = reinterpret_cast<const uint8_t*>(smem); L.cls = T.off_cls; L.pool = T.off_pool; L.ent = T.off_ent;
+  L.csh = GENERAL ? T.cshift : 0u;
   return L;
 }
 
@@ -248,11 +254,12 @@ __device__ __forceinline__ void load_pair(const uint8_t* __restrict__ in, uint64
   }
 }
 
+template <bool GENERAL>
 __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t nseg,
                           const uint64_t* __restrict__ seg_pos, const uint16_t* __restrict__ seg_state,
                           uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
+  Lds L = stage_tables<GENERAL>(T, smem);
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nseg) return;
   uint64_t pos = seg_pos[k];
@@ -347,10 +354,11 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
 }
 
 // sequential run over the head of a shard (bytes before the first synchronised segment)
+template <bool GENERAL>
 __global__ void k_head(const uint8_t* __restrict__ in, uint64_t n, uint64_t head_len, uint32_t h,
                        uint16_t* __restrict__ chk, Flags* flags, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
+  Lds L = stage_tables<GENERAL>(T, smem);
   if (blockIdx.x || threadIdx.x) return;
   const uint32_t dead = T.deadh;
   for (uint64_t pos = 0; pos < head_len; ++pos) {
@@ -459,7 +467,7 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
                           uint8_t* __restrict__ bs_mstart, uint32_t Lc, PieceRec* __restrict__ prec,
                           uint16_t* __restrict__ merge_piece, uint32_t* __restrict__ ctot, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
+  Lds L = stage_tables<WIDE>(T, smem);
   // per-lane staging behind the table image: 8 piece records (64 B) and 8 piece-start checkpoints (16 B), so
   // that both move as whole aligned lines instead of scattered 1-4 byte accesses
   uint4* lrec = reinterpret_cast<uint4*>(smem + ((T.packed_words + 3) & ~3u)) + (size_t)threadIdx.x * 5;
@@ -658,7 +666,7 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
                           const uint32_t* __restrict__ len, const uint16_t* __restrict__ merge_piece,
                           const uint32_t* __restrict__ ctot, PieceRec* __restrict__ prec, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
+  Lds L = stage_tables<WIDE>(T, smem);
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= nblk) return;
   const uint64_t bstart = (uint64_t)m * blk;
@@ -675,7 +683,8 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     uint32_t w[16], bo[BOW];
     load_piece(in, n, pstart, w);
     const uint32_t hh = reinterpret_cast<const uint32_t*>(chk)[pstart >> 6];
-    piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
+    if constexpr (WIDE) piece_forward(w, hh & 0xFFFFu, L, bo);
+    else piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
     mask_tail(bo, plen, T.nullrow);
     const uint32_t leaf_end = leaf >> 2;
     uint32_t lmid = 0, shi = 0;
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
   constexpr bool WIDE = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  Lds L = stage_tables(T, smem);
+  Lds L = stage_tables<WIDE>(T, smem);
   // the sweeps address LDS absolutely (16-bit row offsets, staging cursors): the image must sit at LDS address 0
   if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -766,7 +775,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       if (!valid) oend = ostart;
     }
     const uint32_t hh = valid ? reinterpret_cast<const uint32_t*>(chk)[piece] : T.deadh * 0x10001u;
-    piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
+    if constexpr (WIDE) piece_forward(w, hh & 0xFFFFu, L, bo);
+    else piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
     mask_tail(bo, plen, T.nullrow);
     const uint32_t leaf_end4 = (rec.leaf & 0xFFu) * 4, leaf_mid4 = ((rec.leaf >> 8) & 0xFFu) * 4, len_hi = rec.leaf >> 16;
     const unsigned long long vmask = __ballot(valid);
@@ -878,7 +888,7 @@ struct Stage {
   DevTables T{};
   size_t lds_bytes = 0;                                // packed table image
   size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
-  bool wide = false;                                   // some back entry needs the escaped wide form
+  bool general = false;                                   // wide back entries or > 64 byte classes: run the GENERAL kernel instances
   bool short_consts = true;                            // every path constant is at most EMIT_INLINE bytes
 };
 
@@ -961,7 +971,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t* sync_next = (const uint32_t*)c; c += (size_t)nsync * C * 4;
   const uint32_t* sync_state = (const uint32_t*)c; c += (size_t)nsync * 4;
   if (c > end) return setErr(KX_E_BLOB, "truncated stage body");
-  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C * 4 + 512 > 0xFFF0)
+  if (nstates == 0 || C == 0 || Lm == 0 || Lm > 254 || (size_t)(nstates + 1) * C * 4 + OFF_FWD > 0xFFF0)
     return setErr(KX_E_BLOB, "program outside engine limits (states x classes / leaves)");
 
   S.nstates = nstates; S.nclasses = C; S.q0 = q0; S.maxleaves = Lm;
@@ -970,7 +980,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   std::vector<uint32_t> rowoff(nback), ent, wlen, woff;
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
     const bool wide = dlen >= 127 || poff >= (1u << 13);
-    if (wide) S.wide = true;
+    if (wide) S.general = true;
     if (dlen - copy > (uint32_t)EMIT_INLINE) S.short_consts = false;
     ent.push_back((copy ? 0u : 1u) | (parent << 2) | ((wide ? 0u : poff) << 10) | (dlen > copy ? 1u << 23 : 0u) |
                   ((wide ? 127u : dlen) << 24));
@@ -994,16 +1004,18 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   const uint32_t nullrow_idx = (uint32_t)ent.size();
   for (uint32_t j = 0; j < Lm; ++j) pushEnt(j, 0, 0, 0);
   for (uint32_t j = 0; j < Lm; ++j) pushEnt(0, 0, 0, 0);
-  // LDS image: cls4 (512 B, at LDS address 0: the hand-scheduled sweeps read it with no base) | fwd | ent | pool
+  // LDS image: cls4 (256 B, at LDS address 0: the hand-scheduled sweeps read it with no base) | fwd | ent | pool
   const uint32_t off_fwd = OFF_FWD, fwd_bytes = (nstates + 1) * C * 4;
   const uint32_t off_ent = off_fwd + fwd_bytes;
   if ((size_t)off_ent + ent.size() * 4 > 65532)
     return setErr(KX_E_BLOB, "program tables exceed the engine's 16-bit LDS addressing (states x classes + path table > 64 KiB)");
   const uint32_t deadh = off_fwd + nstates * C * 4;    // handle of the absorbing "no transition" state
-  std::vector<uint32_t> packed(128 + (size_t)(nstates + 1) * C);
-  for (int b = 0; b < 256; ++b) ((uint16_t*)packed.data())[b] = (uint16_t)(cls[b] * 4);
+  const uint32_t cshift = C <= 64 ? 0u : 2u;           // class·4 fits a byte up to 64 classes
+  if (cshift) S.general = true;
+  std::vector<uint32_t> packed(OFF_FWD / 4 + (size_t)(nstates + 1) * C);
+  for (int b = 0; b < 256; ++b) ((uint8_t*)packed.data())[b] = (uint8_t)(cshift ? cls[b] : cls[b] * 4);
   {
-    uint32_t* fwd = packed.data() + 128;
+    uint32_t* fwd = packed.data() + OFF_FWD / 4;
     for (uint32_t q = 0; q < nstates; ++q)
       for (uint32_t k = 0; k < C; ++k) {
         uint16_t d = delta[(size_t)q * C + k];
@@ -1072,7 +1084,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   T.packed = (const uint32_t*)(d + o_packed); T.packed_words = (uint32_t)packed.size();
   T.off_ent = off_ent; T.off_pool = off_pool; T.off_cls = off_cls;
   T.wlen = (const uint32_t*)(d + o_wl); T.woff = (const uint32_t*)(d + o_wo);
-T.nstates = nstates; T.nclasses = C; T.off_fwd = off_fwd; T.q0h = off_fwd + q0 * C * 4; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow;
+T.nstates = nstates; T.nclasses = C; T.off_fwd = off_fwd; T.q0h = off_fwd + q0 * C * 4; T.maxleaves = Lm; T.deadh = deadh; T.nullrow = nullrow; T.cshift = cshift;
   T.cls = (const uint8_t*)(d + o_cls); T.nleaves = (const uint8_t*)(d + o_nl); T.fin_leaf = (const uint8_t*)(d + o_fl);
   T.sync16 = (const uint16_t*)(d + o_sn); T.nsync = nsync; T.sync_multi = nmulti; T.sync_words = (uint32_t)(sync_bytes / 4);
   T.init_off = (const uint32_t*)(d + o_io); T.init_len = (const uint32_t*)(d + o_il);
@@ -1122,8 +1134,10 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
                   : tab + 8 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 8 : 4;
   if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12 || v == 16) && v < p->emit_waves) p->emit_waves = v; }
   if (tab + 4 * (size_t)EMIT_WAVE_LDS > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
-  int rc = setLds((const void*)k_forward, lds); if (rc) { kx_free(p); return rc; }
-  rc = setLds((const void*)k_head, lds); if (rc) { kx_free(p); return rc; }
+  int rc = setLds((const void*)k_forward<false>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_forward<true>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_head<false>, lds); if (rc) { kx_free(p); return rc; }
+  rc = setLds((const void*)k_head<true>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_backlen<32, false>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_backlen<32, true>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_backlen<256, false>, tab + 1024 * 80); if (rc) { kx_free(p); return rc; }
@@ -1133,7 +1147,7 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   if (slds) { rc = setLds((const void*)k_sync<true>, slds); if (rc) { kx_free(p); return rc; } }
   const size_t elds = tab + (size_t)p->emit_waves * EMIT_WAVE_LDS;
   bool anywide = false;
-  for (auto& s : p->stages) anywide = anywide || s.wide;
+  for (auto& s : p->stages) anywide = anywide || s.general;
 #define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, 0>, elds), rc = rc ? rc : setLds((const void*)k_emit<WV, 2>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, 1>, elds) : 0))
   rc = p->emit_waves == 16 ? KX_EMIT_ATTR(16) : p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
 #undef KX_EMIT_ATTR
@@ -1240,7 +1254,7 @@ int kx_shard_forward(kx_shard* s, kx_fwd_summary* out) {
     hipLaunchKernelGGL((k_sync<false>), dim3(grid), dim3(bt), 0, s->stream, s->in, s->n, s->seg, s->nseg, s->is_first,
                        s->seg_pos, s->seg_state, s->flags, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
-  hipLaunchKernelGGL(k_forward, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->nseg, s->seg_pos,
+  hipLaunchKernelGGL(S.general ? k_forward<true> : k_forward<false>, dim3(grid), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->nseg, s->seg_pos,
                      s->seg_state, s->chk, s->flags, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[2], s->stream));
   HIPCHECK(hipGetLastError());
@@ -1271,7 +1285,7 @@ int kx_shard_fix_head(kx_shard* s, uint32_t incoming_state, kx_fwd_summary* out)
     if (incoming_state > S.nstates) return setErr(KX_E_ARG, "incoming state out of range");
     const bool timing = p->cfg.collect_timing;
     if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len,
+    hipLaunchKernelGGL(S.general ? k_head<true> : k_head<false>, dim3(1), dim3(64), S.lds_bytes, s->stream, s->in, s->n, s->head_len,
                        OFF_FWD + incoming_state * S.nclasses * 4, s->chk, s->flags, S.T);
     if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
     HIPCHECK(hipGetLastError());
@@ -1308,8 +1322,8 @@ int kx_shard_backward(kx_shard* s, kx_bwd_summary* out) {
   hipLaunchKernelGGL((k_backlen<MC, WD>), dim3(grid), dim3(bt), blds, s->stream, s->in, s->n, s->seg, s->nblk, s->chk, \
                      s->flags, s->is_last, s->bs_start, s->bs_len, s->bs_merged, s->bs_mstart, s->Lc, s->prec,        \
                      s->merge_piece, s->ctot, S.T)
-  if (s->Lc <= 32) { if (S.wide) KX_LAUNCH_BACKLEN(32, true); else KX_LAUNCH_BACKLEN(32, false); }
-  else { if (S.wide) KX_LAUNCH_BACKLEN(256, true); else KX_LAUNCH_BACKLEN(256, false); }
+  if (s->Lc <= 32) { if (S.general) KX_LAUNCH_BACKLEN(32, true); else KX_LAUNCH_BACKLEN(32, false); }
+  else { if (S.general) KX_LAUNCH_BACKLEN(256, true); else KX_LAUNCH_BACKLEN(256, false); }
 #undef KX_LAUNCH_BACKLEN
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
@@ -1343,7 +1357,7 @@ int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
                      s->bs_merged, s->bs_mstart, s->Lc, s->E, s->len, s->wsum);
   hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, s->stream, s->ngroups, s->wsum, s->woff, s->flags);
   hipLaunchKernelGGL(k_scan_blocks, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, s->len, s->woff, s->off);
-  if (S.wide)
+  if (S.general)
     hipLaunchKernelGGL((k_fixtail<true>), dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk,
                        s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, S.T);
   else
@@ -1393,7 +1407,7 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
                      s->prec, s->ctot, s->off, s->flags, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
-  const int mode = S.wide ? 1 : S.short_consts ? 2 : 0;
+  const int mode = S.general ? 1 : S.short_consts ? 2 : 0;
   if (mode == 1) { if (W == 16) KX_LAUNCH_EMIT(16, 1); else if (W == 12) KX_LAUNCH_EMIT(12, 1); else if (W == 8) KX_LAUNCH_EMIT(8, 1); else KX_LAUNCH_EMIT(4, 1); }
   else if (mode == 2) { if (W == 16) KX_LAUNCH_EMIT(16, 2); else if (W == 12) KX_LAUNCH_EMIT(12, 2); else if (W == 8) KX_LAUNCH_EMIT(8, 2); else KX_LAUNCH_EMIT(4, 2); }
   else { if (W == 16) KX_LAUNCH_EMIT(16, 0); else if (W == 12) KX_LAUNCH_EMIT(12, 0); else if (W == 8) KX_LAUNCH_EMIT(8, 0); else KX_LAUNCH_EMIT(4, 0); }

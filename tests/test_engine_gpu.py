@@ -1,6 +1,7 @@
 """GPU: parity of the HIP engine (through the C ABI) with the CPU oracle — bit-exact, always."""
 import hashlib
 import os
+import random
 
 import pytest
 from conftest import GOLDEN, blob_of, line_expected, line_input, same_modulo_trailing_newlines
@@ -140,6 +141,34 @@ def test_long_constants_use_the_wide_entry_form_and_oversize_pieces():
     src = 'main := (~/a/ "%s" | /b/ | ~/c/ "<%s>")*\n' % (big, "y" * 130)
     blob = blob_of(src)
     for data in [b"a", b"abcab" * 50, b"b" * 1000 + b"a" + b"b" * 1000, b"c" * 64 + b"a" * 64, b"abc" * 3000]:
+        for seg in (64, 4096):
+            got, want = both(blob, data, segment_bytes=seg)
+            assert got == want, (len(data), seg)
+
+
+def test_constant_on_every_symbol_overflows_the_job_slots_and_the_staging_buffer():
+    """k_emit notes constants in a fixed number of per-lane job slots and assembles output in a fixed
+    staging buffer: a program that appends a constant on every symbol exhausts both (second sweep that
+    copies constants in place; several flush rounds per wave; pieces written straight to global memory)."""
+    rng = random.Random(11)
+    text = bytes(rng.choice(b"abcdefgh") for _ in range(70000))
+    for const in ("<->", "=" * 40, "#" * 100):   # 4x, 41x and 101x expansion (the last exceeds the staging buffer per piece)
+        blob = blob_of('main := (/[a-d]/ "%s" | /[e-h]/)*\n' % const)
+        for data in [text[:1], text[:63], text[:64], text[:4097], text]:
+            for seg in (64, 4096):
+                got, want = both(blob, data, segment_bytes=seg)
+                assert got == want, (const[:3], len(data), seg)
+
+
+def test_more_than_64_byte_classes_run_the_general_kernel_instances():
+    """Up to 64 byte classes the class table holds class*4 in one byte; beyond that the GENERAL kernel
+    instances shift the class index (DevTables::cshift)."""
+    alts = " | ".join('/%s/ "%d;"' % (("\\x%02x" % b), b) for b in range(33, 127))
+    blob = blob_of("main := (%s | ~/ /)*\n" % alts)
+    assert oracle.info(blob)["nclasses"] > 64
+    rng = random.Random(5)
+    text = bytes(rng.choice(range(32, 127)) for _ in range(50000))
+    for data in [b"", text[:5], text[:200], text]:
         for seg in (64, 4096):
             got, want = both(blob, data, segment_bytes=seg)
             assert got == want, (len(data), seg)

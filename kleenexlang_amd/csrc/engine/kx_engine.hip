@@ -60,9 +60,9 @@ constexpr uint32_t OFF_FWD = 256;         // the table image starts with the 256
 constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
 constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
-constexpr int EMIT_INLINE = 2;            // k_emit: constants up to this length are written in place, not listed
-constexpr int EMIT_JOBS = 4096;           // k_emit: bytes of constant-copy job slots per wave (4 B each, shared out among a round's lanes)
-constexpr int EMIT_WAVE_LDS = EMIT_STG + 16 + EMIT_JOBS;
+constexpr int EMIT_JOBS_MIN = 4096;       // k_emit: bytes of constant-copy job slots per wave (4 B each, shared out among a
+constexpr int EMIT_JOBS_MAX = 16384;      //         round's lanes): as much as the LDS left over by the tables allows
+constexpr int EMIT_WAVE_LDS_MIN = EMIT_STG + 16 + EMIT_JOBS_MIN;
 
 // ------------------------------------------------------------------ device-side program view
 // The table image is copied verbatim into LDS (at LDS address 0 of the dynamic segment) and is
@@ -732,21 +732,20 @@ __device__ __forceinline__ void emit_step_gen(const uint32_t (&bo)[BOW], const u
   }
 }
 
-template <int WAVES, int MODE>   // MODE 0: plain; 1: wide back entries; 2: every constant ≤ EMIT_INLINE bytes → written in place
+template <int WAVES, bool WIDE>   // WIDE: the GENERAL instance (wide back entries / class shift), compiler-scheduled sweeps
 __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
                                                      const unsigned long long* __restrict__ off, const Flags* __restrict__ flags,
-                                                     uint32_t init_shift,
+                                                     uint32_t jbytes, uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
-  constexpr bool WIDE = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables<WIDE>(T, smem);
   // the sweeps address LDS absolutely (16-bit row offsets, staging cursors): the image must sit at LDS address 0
   if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t stga = ((T.packed_words + 3) & ~3u) * 4 + wave * EMIT_WAVE_LDS;   // LDS address of this wave's staging area
+  const uint32_t stga = ((T.packed_words + 3) & ~3u) * 4 + wave * (EMIT_STG + 16 + jbytes);   // LDS address of this wave's staging area
   uint8_t* stg = (uint8_t*)smem + stga;
   const uint32_t jarea = stga + EMIT_STG + 16;
   if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pb(T.init_off[init_leaf] + threadIdx.x);
@@ -814,50 +813,48 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       const uint32_t lastl = first + cnt - 1;
       const bool active = lane >= first && lane <= lastl;
       const uint32_t oe = stga + (uint32_t)(oend - abase);   // LDS address one past the piece's staged output
-      // job slots: EMIT_JOBS/4 four-byte slots dealt out evenly to the round's lanes, slot k of a lane at
+      // job slots: jbytes/4 four-byte slots dealt out evenly to the round's lanes, slot k of a lane at
       // jfirst + k*stride (bank-conflict free); the last slot is a sink that marks overflow
-      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((EMIT_JOBS / 4) / cnt - 1) * js;
+      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((jbytes / 4) / cnt - 1) * js;
       uint32_t jp = jfirst;
       // sweep: copied bytes into staging, constants into the lane's job slots (or in place)
       if (active) {
-        if constexpr (MODE == 0) {
+        if constexpr (!WIDE) {
           piece_sweep2(bo, w, leaf_end4, oe, leaf_mid4, oe - len_hi, jp, js, jlast);
         } else {
           uint32_t leaf = leaf_end4, o = oe;
           static_for<0, PIECE>([&](auto ic) {
             constexpr int t = PIECE - 1 - decltype(ic)::value;
-            emit_step_gen<t, WIDE, MODE == 2 ? 1 : 0>(bo, w, leaf, o, jp, js, jlast, L, T);
+            emit_step_gen<t, WIDE, 0>(bo, w, leaf, o, jp, js, jlast, L, T);
           });
         }
       }
-      if constexpr (MODE != 2) {
-        // a lane that ran out of job slots sweeps once more, copying its constants in place
-        const bool ovf = active && jp == jlast;
-        if (__any(ovf)) {
-          if (ovf) {
-            uint32_t leaf = leaf_end4, o = oe, jq = 0;
-            static_for<0, PIECE>([&](auto ic) {
-              constexpr int t = PIECE - 1 - decltype(ic)::value;
-              emit_step_gen<t, WIDE, 1>(bo, w, leaf, o, jq, 0u, 0u, L, T);
-            });
-            jp = jfirst;
-          }
+      // a lane that ran out of job slots sweeps once more, copying its constants in place
+      const bool ovf = active && jp == jlast;
+      if (__any(ovf)) {
+        if (ovf) {
+          uint32_t leaf = leaf_end4, o = oe, jq = 0;
+          static_for<0, PIECE>([&](auto ic) {
+            constexpr int t = PIECE - 1 - decltype(ic)::value;
+            emit_step_gen<t, WIDE, 1>(bo, w, leaf, o, jq, 0u, 0u, L, T);
+          });
+          jp = jfirst;
         }
-        wave_lds_fence();
-        // constants: every lane copies the ones its own piece noted
-        const uint32_t nj = active ? (jp - jfirst) / js : 0u;
-        for (uint32_t k = 0; __any(k < nj); ++k) {
-          if (k < nj) {
-            const uint32_t jb = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jfirst + k * js);
-            const uint32_t a = jb & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
-            const uint32_t d = stga + (((jb >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
-            uint8_t* dst = (uint8_t*)smem + d;
-            const uint8_t* sp = L.base + L.pool + src;
-            uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
-            for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
-            if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
-            if (l & 1) dst[i] = sp[i];
-          }
+      }
+      wave_lds_fence();
+      // constants: every lane copies the ones its own piece noted
+      const uint32_t nj = active ? (jp - jfirst) / js : 0u;
+      for (uint32_t k = 0; __any(k < nj); ++k) {
+        if (k < nj) {
+          const uint32_t jb = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jfirst + k * js);
+          const uint32_t a = jb & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
+          const uint32_t d = stga + (((jb >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
+          uint8_t* dst = (uint8_t*)smem + d;
+          const uint8_t* sp = L.base + L.pool + src;
+          uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
+          for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
+          if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
+          if (l & 1) dst[i] = sp[i];
         }
       }
       wave_lds_fence();
@@ -889,7 +886,6 @@ struct Stage {
   size_t lds_bytes = 0;                                // packed table image
   size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
   bool general = false;                                   // wide back entries or > 64 byte classes: run the GENERAL kernel instances
-  bool short_consts = true;                            // every path constant is at most EMIT_INLINE bytes
 };
 
 struct Arena {  // grow-only device workspace, reused across runs
@@ -924,7 +920,7 @@ struct kx_program {
   bool have_events = false;
   kx_shard* live = nullptr;
   int ncu = 256;
-  int emit_waves = 4;
+  int emit_waves = 4; uint32_t emit_jbytes = EMIT_JOBS_MIN;
 };
 
 struct kx_shard {
@@ -981,7 +977,6 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
     const bool wide = dlen >= 127 || poff >= (1u << 13);
     if (wide) S.general = true;
-    if (dlen - copy > (uint32_t)EMIT_INLINE) S.short_consts = false;
     ent.push_back((copy ? 0u : 1u) | (parent << 2) | ((wide ? 0u : poff) << 10) | (dlen > copy ? 1u << 23 : 0u) |
                   ((wide ? 127u : dlen) << 24));
     wlen.push_back(dlen); woff.push_back(poff);
@@ -1130,10 +1125,14 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   // k_emit: as many waves per CU as the LDS left over by the tables allows (one workgroup per CU)
   const size_t lds_cap = 160 * 1024;
   const size_t tab = (lds + 15) & ~(size_t)15;
-  p->emit_waves = tab + 16 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 16 : tab + 12 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 12
-                  : tab + 8 * (size_t)EMIT_WAVE_LDS <= lds_cap ? 8 : 4;
-  if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12 || v == 16) && v < p->emit_waves) p->emit_waves = v; }
-  if (tab + 4 * (size_t)EMIT_WAVE_LDS > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
+  // (the kernel needs more than 128 VGPRs, so 12 waves — three per SIMD — is the most a CU can hold)
+  p->emit_waves = tab + 12 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 12 : tab + 8 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 8 : 4;
+  if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12) && v < p->emit_waves) p->emit_waves = v; }
+  if (tab + 4 * (size_t)EMIT_WAVE_LDS_MIN > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
+  {
+    size_t j = ((lds_cap - tab) / p->emit_waves - EMIT_STG - 16) & ~(size_t)255;
+    p->emit_jbytes = (uint32_t)(j > EMIT_JOBS_MAX ? EMIT_JOBS_MAX : j);
+  }
   int rc = setLds((const void*)k_forward<false>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_forward<true>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_head<false>, lds); if (rc) { kx_free(p); return rc; }
@@ -1145,11 +1144,11 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   rc = setLds((const void*)k_fixtail<false>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_fixtail<true>, lds); if (rc) { kx_free(p); return rc; }
   if (slds) { rc = setLds((const void*)k_sync<true>, slds); if (rc) { kx_free(p); return rc; } }
-  const size_t elds = tab + (size_t)p->emit_waves * EMIT_WAVE_LDS;
+  const size_t elds = tab + (size_t)p->emit_waves * (EMIT_STG + 16 + p->emit_jbytes);
   bool anywide = false;
   for (auto& s : p->stages) anywide = anywide || s.general;
-#define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, 0>, elds), rc = rc ? rc : setLds((const void*)k_emit<WV, 2>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, 1>, elds) : 0))
-  rc = p->emit_waves == 16 ? KX_EMIT_ATTR(16) : p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
+#define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, false>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, true>, elds) : 0))
+  rc = p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
 #undef KX_EMIT_ATTR
   if (rc) { kx_free(p); return rc; }
   *prog = p;
@@ -1402,15 +1401,13 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   const int W = p->emit_waves;
   uint64_t want = (nwi + W - 1) / W;
   const uint32_t grid = (uint32_t)(want < (uint64_t)p->ncu ? want : (uint64_t)p->ncu);
-  const size_t elds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)W * EMIT_WAVE_LDS;
+  const size_t elds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)W * (EMIT_STG + 16 + p->emit_jbytes);
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
-                     s->prec, s->ctot, s->off, s->flags, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
-  const int mode = S.general ? 1 : S.short_consts ? 2 : 0;
-  if (mode == 1) { if (W == 16) KX_LAUNCH_EMIT(16, 1); else if (W == 12) KX_LAUNCH_EMIT(12, 1); else if (W == 8) KX_LAUNCH_EMIT(8, 1); else KX_LAUNCH_EMIT(4, 1); }
-  else if (mode == 2) { if (W == 16) KX_LAUNCH_EMIT(16, 2); else if (W == 12) KX_LAUNCH_EMIT(12, 2); else if (W == 8) KX_LAUNCH_EMIT(8, 2); else KX_LAUNCH_EMIT(4, 2); }
-  else { if (W == 16) KX_LAUNCH_EMIT(16, 0); else if (W == 12) KX_LAUNCH_EMIT(12, 0); else if (W == 8) KX_LAUNCH_EMIT(8, 0); else KX_LAUNCH_EMIT(4, 0); }
+                     s->prec, s->ctot, s->off, s->flags, p->emit_jbytes, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+  if (S.general) { if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
+  else { if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }
 #undef KX_LAUNCH_EMIT
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());

@@ -57,6 +57,7 @@ typedef struct kx_stats {
   uint64_t in_bytes, out_bytes;
   float kernel_ms[KX_NKERNELS]; /* HIP-event time of each kernel group (last stage run)      */
   float total_ms;               /* first launch → last kernel done, all stages               */
+  uint32_t emit_overflow_pieces; /* output stage: pieces that needed a second sweep (last stage run) */
 } kx_stats;
 
 /* tuning knobs (0 = default) */

@@ -59,9 +59,8 @@ constexpr int HALF = 32;                  // bytes between state checkpoints (tw
 constexpr uint32_t OFF_FWD = 256;         // the table image starts with the 256-byte class table; state rows follow
 constexpr uint64_t UNSYNC = ~0ull;
 constexpr uint64_t NOFAIL = ~0ull;
-constexpr int EMIT_STG = 6144;            // k_emit: staging bytes per wave (one wave-iteration of apache_log fits)
-constexpr int EMIT_JOBS_MIN = 4096;       // k_emit: bytes of constant-copy job slots per wave (4 B each, shared out among a
-constexpr int EMIT_JOBS_MAX = 16384;      //         round's lanes): as much as the LDS left over by the tables allows
+constexpr int EMIT_STG = 6144;            // k_emit: least staging bytes per wave (one wave-iteration of apache_log fits)
+constexpr int EMIT_JOBS_MIN = 4096;       // k_emit: least bytes of constant-copy job slots per wave (4 B each)
 constexpr int EMIT_WAVE_LDS_MIN = EMIT_STG + 16 + EMIT_JOBS_MIN;
 
 // ------------------------------------------------------------------ device-side program view
@@ -143,6 +142,8 @@ struct Flags {               // one per shard, device memory
   uint32_t unsynced;
   unsigned long long total_len;
   uint32_t first_merged;
+  uint32_t emit_ovf;         // k_emit: pieces whose constants did not fit their job slots
+  uint32_t emit_kmax;        // k_emit_probe: most constants met in one sampled piece
   uint32_t pad;
 };
 
@@ -443,16 +444,18 @@ __device__ __forceinline__ uint32_t walk_len(const uint32_t (&bo)[BOW], uint32_t
 }
 // The same walk, also reporting where it stood in the middle of the piece (leaf entering step 31 and
 // the bytes appended by steps 63..32): k_emit starts its second dependency chain there.
-template <bool WIDE>
+template <bool WIDE, bool COUNT = false>   // COUNT: also count the steps that append a constant
 __device__ __forceinline__ uint32_t walk_len_mid(const uint32_t (&bo)[BOW], uint32_t& leaf, uint32_t& leaf_mid, uint32_t& sum_hi,
-                                                 const Lds& L, const DevTables& T) {
-  uint32_t sum = 0;
+                                                 const Lds& L, const DevTables& T, uint32_t* nconst = nullptr) {
+  uint32_t sum = 0, k = 0;
   static_for<0, PIECE>([&](auto ic) {
     constexpr int t = PIECE - 1 - decltype(ic)::value;
     const uint32_t a = BO_GET_DEP(bo, t, leaf) + leaf;
     const uint32_t e = L.w(a); sum += ent_dlen<WIDE>(e, a, L, T); leaf = E_LEAF4(e); tie(leaf, sum);
+    if constexpr (COUNT) { k += E_HASCONST(e); tie(leaf, k); }
     if constexpr (t == HALF) { leaf_mid = leaf; sum_hi = sum; }
   });
+  if constexpr (COUNT) *nconst = k;
   return sum;
 }
 // piece record word: end leaf | leaf in the middle << 8 | min(bytes of the upper half, 0xFFFF) << 16
@@ -660,11 +663,13 @@ __global__ void k_shard_map(uint32_t nblk, uint32_t nleaves_end, const uint8_t* 
 // With the block's end leaf E known, walk the unresolved tail pieces [merge_piece, npieces) again
 // and write their end leaf and offset in the convention of k_backlen:
 //   output offset of piece p inside its block = ctot[m] - pcum[p].
+// The same walk counts the constants of the pieces it visits, plus those of the block's first piece:
+// a sample (one or two pieces per block) from which k_emit's job slots are dimensioned.
 template <bool WIDE>
 __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
                           const uint32_t* __restrict__ len, const uint16_t* __restrict__ merge_piece,
-                          const uint32_t* __restrict__ ctot, PieceRec* __restrict__ prec, DevTables T) {
+                          const uint32_t* __restrict__ ctot, PieceRec* __restrict__ prec, Flags* flags, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables<WIDE>(T, smem);
   uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,12 +677,15 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   const uint64_t bstart = (uint64_t)m * blk;
   const uint64_t bend = bstart + blk < n ? bstart + blk : n;
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
-  const uint32_t mp = merge_piece[m];
-  if (mp >= npieces) return;
+  const uint32_t mp = merge_piece[m] < npieces ? merge_piece[m] : npieces;
   const uint64_t piece0 = bstart >> 6;
-  uint32_t leaf = (uint32_t)E[m] * 4, suffix = 0;
+  uint32_t leaf = (uint32_t)E[m] * 4, suffix = 0, kmax = 0;
   const int32_t base = (int32_t)ctot[m] - (int32_t)len[m];
-  for (uint32_t p = npieces; p-- > mp;) {
+  const uint32_t ntail = npieces - mp, nvisit = ntail + (mp > 0 ? 1u : 0u);
+  for (uint32_t i = 0; i < nvisit; ++i) {
+    const bool tail = i < ntail;
+    const uint32_t p = tail ? npieces - 1 - i : 0u;
+    if (!tail) leaf = (prec[piece0].leaf & 0xFFu) * 4;   // sample only: piece 0 was finished by k_backlen
     const uint64_t pstart = bstart + (uint64_t)p * PIECE;
     const int plen = (int)(bend - pstart < PIECE ? bend - pstart : PIECE);
     uint32_t w[16], bo[BOW];
@@ -687,10 +695,12 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     else piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
     mask_tail(bo, plen, T.nullrow);
     const uint32_t leaf_end = leaf >> 2;
-    uint32_t lmid = 0, shi = 0;
-    suffix += walk_len_mid<WIDE>(bo, leaf, lmid, shi, L, T);
-    prec[piece0 + p] = PieceRec{base + (int32_t)suffix, rec_word(leaf_end, lmid, shi)};
+    uint32_t lmid = 0, shi = 0, k = 0;
+    suffix += walk_len_mid<WIDE, true>(bo, leaf, lmid, shi, L, T, &k);
+    kmax = k > kmax ? k : kmax;
+    if (tail) prec[piece0 + p] = PieceRec{base + (int32_t)suffix, rec_word(leaf_end, lmid, shi)};
   }
+  if (kmax > flags->emit_kmax) atomicMax(&flags->emit_kmax, kmax);
 }
 
 // ------------------------------------------------------------------------------- k_emit
@@ -737,17 +747,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
-                                                     const unsigned long long* __restrict__ off, const Flags* __restrict__ flags,
-                                                     uint32_t jbytes, uint32_t init_shift,
+                                                     const unsigned long long* __restrict__ off, Flags* __restrict__ flags,
+                                                     uint32_t stgb, uint32_t jbytes, uint32_t maxcnt, uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables<WIDE>(T, smem);
   // the sweeps address LDS absolutely (16-bit row offsets, staging cursors): the image must sit at LDS address 0
   if ((uint32_t)(uintptr_t)smem != 0u) __builtin_trap();
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t stga = ((T.packed_words + 3) & ~3u) * 4 + wave * (EMIT_STG + 16 + jbytes);   // LDS address of this wave's staging area
+  const uint32_t stga = ((T.packed_words + 3) & ~3u) * 4 + wave * (stgb + 16 + jbytes);   // LDS address of this wave's staging area
   uint8_t* stg = (uint8_t*)smem + stga;
-  const uint32_t jarea = stga + EMIT_STG + 16;
+  const uint32_t jarea = stga + stgb + 16;
   if (is_first && blockIdx.x == 0 && threadIdx.x < init_shift) out[threadIdx.x] = L.pb(T.init_off[init_leaf] + threadIdx.x);
   if (is_first && blockIdx.x == 0 && init_shift > blockDim.x)
     for (uint32_t i = blockDim.x + threadIdx.x; i < init_shift; i += blockDim.x) out[i] = L.pb(T.init_off[init_leaf] + i);
@@ -784,9 +794,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
     while (first < nvalid) {
       const uint64_t gs = __shfl(ostart, first);
       const uint64_t abase = gs & ~15ull;
-      const bool fits = valid && lane >= first && (oend - abase) <= (uint64_t)EMIT_STG && len_hi != 0xFFFFu;
+      const bool fits = valid && lane >= first && (oend - abase) <= (uint64_t)stgb && len_hi != 0xFFFFu;
       const unsigned long long fm = __ballot(fits) >> first;
-      const uint32_t cnt = fm == ~0ull ? 64u - first : (uint32_t)__builtin_ctzll(~fm);   // leading run of fitting lanes
+      uint32_t cnt = fm == ~0ull ? 64u - first : (uint32_t)__builtin_ctzll(~fm);   // leading run of fitting lanes
+      if (cnt > maxcnt) cnt = maxcnt;   // (the job slots are dealt out for at most maxcnt lanes per round)
       if (cnt == 0) {
         // a single piece larger than the staging area: its lane writes straight to global memory
         if (lane == first) {
@@ -815,7 +826,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       const uint32_t oe = stga + (uint32_t)(oend - abase);   // LDS address one past the piece's staged output
       // job slots: jbytes/4 four-byte slots dealt out evenly to the round's lanes, slot k of a lane at
       // jfirst + k*stride (bank-conflict free); the last slot is a sink that marks overflow
-      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((jbytes / 4) / cnt - 1) * js;
+      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((jbytes / 4) / maxcnt - 1) * js;
       uint32_t jp = jfirst;
       // sweep: copied bytes into staging, constants into the lane's job slots (or in place)
       if (active) {
@@ -832,6 +843,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       // a lane that ran out of job slots sweeps once more, copying its constants in place
       const bool ovf = active && jp == jlast;
       if (__any(ovf)) {
+        const unsigned long long om = __ballot(ovf);
+        if (lane == (uint32_t)__builtin_ctzll(om)) atomicAdd(&flags->emit_ovf, (uint32_t)__popcll(om));
         if (ovf) {
           uint32_t leaf = leaf_end4, o = oe, jq = 0;
           static_for<0, PIECE>([&](auto ic) {
@@ -920,7 +933,7 @@ struct kx_program {
   bool have_events = false;
   kx_shard* live = nullptr;
   int ncu = 256;
-  int emit_waves = 4; uint32_t emit_jbytes = EMIT_JOBS_MIN;
+
 };
 
 struct kx_shard {
@@ -1125,14 +1138,7 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   // k_emit: as many waves per CU as the LDS left over by the tables allows (one workgroup per CU)
   const size_t lds_cap = 160 * 1024;
   const size_t tab = (lds + 15) & ~(size_t)15;
-  // (the kernel needs more than 128 VGPRs, so 12 waves — three per SIMD — is the most a CU can hold)
-  p->emit_waves = tab + 12 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 12 : tab + 8 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 8 : 4;
-  if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12) && v < p->emit_waves) p->emit_waves = v; }
   if (tab + 4 * (size_t)EMIT_WAVE_LDS_MIN > lds_cap) { kx_free(p); return setErr(KX_E_BLOB, "program tables leave no LDS for the output stage"); }
-  {
-    size_t j = ((lds_cap - tab) / p->emit_waves - EMIT_STG - 16) & ~(size_t)255;
-    p->emit_jbytes = (uint32_t)(j > EMIT_JOBS_MAX ? EMIT_JOBS_MAX : j);
-  }
   int rc = setLds((const void*)k_forward<false>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_forward<true>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_head<false>, lds); if (rc) { kx_free(p); return rc; }
@@ -1144,11 +1150,11 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
   rc = setLds((const void*)k_fixtail<false>, lds); if (rc) { kx_free(p); return rc; }
   rc = setLds((const void*)k_fixtail<true>, lds); if (rc) { kx_free(p); return rc; }
   if (slds) { rc = setLds((const void*)k_sync<true>, slds); if (rc) { kx_free(p); return rc; } }
-  const size_t elds = tab + (size_t)p->emit_waves * (EMIT_STG + 16 + p->emit_jbytes);
+  const size_t elds = lds_cap;   // waves, staging and job slots per wave are chosen per run (output/input ratio)
   bool anywide = false;
   for (auto& s : p->stages) anywide = anywide || s.general;
 #define KX_EMIT_ATTR(WV) (rc = setLds((const void*)k_emit<WV, false>, elds), rc ? rc : (anywide ? setLds((const void*)k_emit<WV, true>, elds) : 0))
-  rc = p->emit_waves == 12 ? KX_EMIT_ATTR(12) : p->emit_waves == 8 ? KX_EMIT_ATTR(8) : KX_EMIT_ATTR(4);
+  rc = KX_EMIT_ATTR(12); rc = rc ? rc : KX_EMIT_ATTR(8); rc = rc ? rc : KX_EMIT_ATTR(4);
 #undef KX_EMIT_ATTR
   if (rc) { kx_free(p); return rc; }
   *prog = p;
@@ -1358,10 +1364,10 @@ int kx_shard_resolve(kx_shard* s, uint32_t end_leaf, uint64_t* out_len) {
   hipLaunchKernelGGL(k_scan_blocks, dim3(s->ngroups), dim3(bt), 0, s->stream, s->nblk, s->len, s->woff, s->off);
   if (S.general)
     hipLaunchKernelGGL((k_fixtail<true>), dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk,
-                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, S.T);
+                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, s->flags, S.T);
   else
     hipLaunchKernelGGL((k_fixtail<false>), dim3(s->ngroups), dim3(bt), S.lds_bytes, s->stream, s->in, s->n, s->seg, s->nblk,
-                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, S.T);
+                       s->chk, s->E, s->len, s->merge_piece, s->ctot, s->prec, s->flags, S.T);
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   uint8_t e0 = 0;
@@ -1398,21 +1404,51 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   const bool timing = p->cfg.collect_timing;
   const uint64_t npieces = (s->n + PIECE - 1) / PIECE;
   const uint64_t nwi = (npieces + 63) / 64;
-  const int W = p->emit_waves;
-  uint64_t want = (nwi + W - 1) / W;
-  const uint32_t grid = (uint32_t)(want < (uint64_t)p->ncu ? want : (uint64_t)p->ncu);
-  const size_t elds = ((S.lds_bytes + 15) & ~(size_t)15) + (size_t)W * (EMIT_STG + 16 + p->emit_jbytes);
+  // Waves per CU (one persistent workgroup each), staging bytes and job-slot bytes per wave.  A wave-iteration
+  // turns 4 KiB of input into ratio x 4 KiB of output; when that fits the staging buffer the iteration is one
+  // sweep + one flush, otherwise every extra round repeats the sweep code for the lanes it did not cover.  The
+  // kernel needs more than 128 VGPRs, so 12 waves (three per SIMD) is the most a CU holds.
+  const size_t lds_cap = 160 * 1024, tab = (S.lds_bytes + 15) & ~(size_t)15;
+  int W = tab + 12 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 12 : tab + 8 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 8 : 4;
+  if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12) && v <= W) W = v; }
+  const size_t per_wave = ((lds_cap - tab) / W) & ~(size_t)255;
+  const uint32_t kmax = s->hflags.emit_kmax;   // most constants in one sampled piece (k_fixtail)
+  // Rounds per iteration R = 1, 2, …: a round covers up to ceil(64/R) lanes, needs staging for their output
+  // (average piece output x 1.08) and kmax+2 job slots per lane
+  // (a lane whose write pointer reaches the last slot counts as overflowed); take the smallest R that fits the wave's LDS.
+  const double olen = 64.0 * (double)s->out_len / (double)(s->n ? s->n : 1);
+  const uint32_t kslots = (kmax < 63 ? kmax : 63) + 2;
+  size_t stgb = 0, jbytes = 0; uint32_t maxcnt = 64;
+  for (uint32_t R = 1; R <= 64; ++R) {
+    const uint32_t c = (64 + R - 1) / R;
+    size_t st = (((size_t)(c * olen * 1.08) + 64) + 255) & ~(size_t)255, jb = ((size_t)c * kslots * 4 + 255) & ~(size_t)255;
+    if (st < 1024) st = 1024;
+    if (st + 16 + jb <= per_wave || c == 1) {
+      maxcnt = c; jbytes = jb; stgb = per_wave - 16 - jb;   // the rest goes to staging (bigger pieces fit, fewer oversize ones)
+      break;
+    }
+  }
+  if (const char* ev = getenv("KX_EMIT_STG")) { size_t v = (size_t)atoi(ev) & ~(size_t)255; if (v >= 1024 && v + 16 + jbytes <= per_wave) stgb = v; }
+  if (stgb > 49152) stgb = 49152;   // job records keep 16 bits of the staging address
+  stgb &= ~(size_t)15;
+  uint64_t wantg = (nwi + W - 1) / W;
+  const uint32_t grid = (uint32_t)(wantg < (uint64_t)p->ncu ? wantg : (uint64_t)p->ncu);
+  const size_t elds = tab + (size_t)W * (stgb + 16 + jbytes);
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
-                     s->prec, s->ctot, s->off, s->flags, p->emit_jbytes, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+                     s->prec, s->ctot, s->off, s->flags, (uint32_t)stgb, (uint32_t)jbytes, maxcnt, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
   if (S.general) { if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
   else { if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }
 #undef KX_LAUNCH_EMIT
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
+  uint32_t ovf = 0;
+  HIPCHECK(hipMemcpyAsync(&ovf, &s->flags->emit_ovf, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCHECK(hipStreamSynchronize(s->stream));
   if (timing) s->stats.kernel_ms[KX_K_EMIT] = evMs(p->ev[0], p->ev[1]);
+  s->stats.emit_overflow_pieces = ovf;
+  if (getenv("KX_DEBUG")) fprintf(stderr, "[kx] emit: W=%d stg=%zu jobs=%zu maxcnt=%u kmax=%u olen=%.1f overflow=%u of %llu pieces\n", W, stgb, jbytes, maxcnt, kmax, olen, ovf, (unsigned long long)npieces);
   return 0;
 }
 

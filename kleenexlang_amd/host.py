@@ -44,11 +44,12 @@ class KxStats(ctypes.Structure):
     _fields_ = [("fail_pos", ctypes.c_uint64), ("fail_stage", ctypes.c_uint32),
                 ("unsynced_segments", ctypes.c_uint32), ("in_bytes", ctypes.c_uint64),
                 ("out_bytes", ctypes.c_uint64), ("kernel_ms", ctypes.c_float * KX_NKERNELS),
-                ("total_ms", ctypes.c_float)]
+                ("total_ms", ctypes.c_float), ("emit_overflow_pieces", ctypes.c_uint32)]
 
     def as_dict(self):
         return {"unsynced_segments": self.unsynced_segments, "in_bytes": self.in_bytes,
                 "out_bytes": self.out_bytes, "total_ms": self.total_ms,
+                "emit_overflow_pieces": self.emit_overflow_pieces,
                 "kernel_ms": {k: self.kernel_ms[i] for i, k in enumerate(KERNEL_NAMES)}}
 
 

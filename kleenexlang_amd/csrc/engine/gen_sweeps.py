@@ -12,9 +12,10 @@ before doing the bookkeeping of the current step.
       (class*4), 1 SDWA add on the chain (next fwd address = e.lo16 + class*4), 1 ds_read_b32, 1 op
       packing the row offset (e.hi16) into bo.  The class table sits at LDS address 0.
 
-  piece_sweep2(bo, w, leafA, oA, leafB, oB, jp, js, jl)
+  piece_sweep2(bo, w, leafA, oA, leafB, oB, jb, jlim)
       backward sweep that places the output: chain A = steps 63..32 from (leafA, oA), chain B = steps
-      31..0 from (leafB, oB); see the step description in kx_engine.hip (k_emit).
+      31..0 from (leafB, oB); see the step description in kx_engine.hip (k_emit).  jb (SGPR, in/out) is
+      the LDS address of the wave's next free job slot, jlim that of the last slot.
 
 The file is generated (python gen_sweeps.py > kx_sweeps.inc) and committed; build.py regenerates it
 when this script is newer.
@@ -92,12 +93,17 @@ def sweep2():
             ap("%s %s, %s" % (wr, e, src))
             ap("s_and_saveexec_b64 %[sv], vcc")
             ap("s_cbranch_execz 1f")
+            # job slot = wave-wide running count + rank among the lanes that note a constant in this step
+            ap("v_mbcnt_lo_u32_b32 %s, exec_lo, 0" % e)
+            ap("v_mbcnt_hi_u32_b32 %s, exec_hi, %s" % (e, e))
+            ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (e, e))
+            ap("v_min_u32 %s, %%[jlim], %s" % (e, e))
             ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
-            ap("ds_write_b32 %%[jp], %s" % a)
-            ap("v_add_u32 %[jp], %[js], %[jp]")
-            ap("v_min_u32 %[jp], %[jp], %[jl]")
+            ap("ds_write_b32 %s, %s" % (e, a))
             ap("1:")
             ap("s_or_b64 exec, exec, %[sv]")
+            ap("s_bcnt1_i32_b64 %[st], vcc")
+            ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
     return L
 
 
@@ -125,14 +131,14 @@ def main():
     tmp = ["eA0", "eA1", "eB0", "eB1", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
     emit_fn(out, "piece_sweep2",
             "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
-            "uint32_t& jp, uint32_t js, uint32_t jl",
-            "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
+            "uint32_t& jb, uint32_t jlim",
+            "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv;",
             sweep2(),
-            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
-                                                       '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jp] "+v"(jp)'],
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
+                                                       '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
-            ['[js] "v"(js)', '[jl] "v"(jl)'],
-            '"vcc", "memory"')
+            ['[jlim] "s"(jlim)'],
+            '"vcc", "scc", "memory"')
 
 
 if __name__ == "__main__":

@@ -143,8 +143,9 @@ struct Flags {               // one per shard, device memory
   unsigned long long total_len;
   uint32_t first_merged;
   uint32_t emit_ovf;         // k_emit: pieces whose constants did not fit their job slots
-  uint32_t emit_kmax;        // k_emit_probe: most constants met in one sampled piece
-  uint32_t pad;
+  uint32_t emit_kmax;        // k_fixtail's sample: most constants met in one piece,
+  uint32_t emit_ksum, emit_kn;   //   constants / pieces over a subsample (their average)
+  uint32_t pad[3];
 };
 
 // Bit-field extract that the scheduler may not issue before `dep` exists.  The sweeps below are one
@@ -663,8 +664,8 @@ __global__ void k_shard_map(uint32_t nblk, uint32_t nleaves_end, const uint8_t* 
 // With the block's end leaf E known, walk the unresolved tail pieces [merge_piece, npieces) again
 // and write their end leaf and offset in the convention of k_backlen:
 //   output offset of piece p inside its block = ctot[m] - pcum[p].
-// The same walk counts the constants of the pieces it visits, plus those of the block's first piece:
-// a sample (one or two pieces per block) from which k_emit's job slots are dimensioned.
+// The same walk counts the constants of the pieces it visits, plus those of every eighth block's first
+// piece: a sample from which k_emit's job slots are dimensioned.
 template <bool WIDE>
 __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t nblk,
                           const uint16_t* __restrict__ chk, const uint8_t* __restrict__ E,
@@ -679,9 +680,9 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
   const uint32_t npieces = (uint32_t)((bend - bstart + PIECE - 1) / PIECE);
   const uint32_t mp = merge_piece[m] < npieces ? merge_piece[m] : npieces;
   const uint64_t piece0 = bstart >> 6;
-  uint32_t leaf = (uint32_t)E[m] * 4, suffix = 0, kmax = 0;
+  uint32_t leaf = (uint32_t)E[m] * 4, suffix = 0, kmax = 0, ksum = 0;
   const int32_t base = (int32_t)ctot[m] - (int32_t)len[m];
-  const uint32_t ntail = npieces - mp, nvisit = ntail + (mp > 0 ? 1u : 0u);
+  const uint32_t ntail = npieces - mp, nvisit = ntail + (mp > 0 && (m & 7u) == 0 ? 1u : 0u);
   for (uint32_t i = 0; i < nvisit; ++i) {
     const bool tail = i < ntail;
     const uint32_t p = tail ? npieces - 1 - i : 0u;
@@ -697,10 +698,11 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
     const uint32_t leaf_end = leaf >> 2;
     uint32_t lmid = 0, shi = 0, k = 0;
     suffix += walk_len_mid<WIDE, true>(bo, leaf, lmid, shi, L, T, &k);
-    kmax = k > kmax ? k : kmax;
+    kmax = k > kmax ? k : kmax; ksum += k;
     if (tail) prec[piece0 + p] = PieceRec{base + (int32_t)suffix, rec_word(leaf_end, lmid, shi)};
   }
   if (kmax > flags->emit_kmax) atomicMax(&flags->emit_kmax, kmax);
+  if ((m & 255u) == 0 && nvisit) { atomicAdd(&flags->emit_ksum, ksum); atomicAdd(&flags->emit_kn, nvisit); }
 }
 
 // ------------------------------------------------------------------------------- k_emit
@@ -711,19 +713,20 @@ __global__ void k_fixtail(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
 // range is known beforehand from the piece records (start = its own record, end = the next piece's
 // start), so the write cursor simply runs down from the end.  Copied input bytes are stored by
 // the walking lane; constants are noted as (entry, cursor) pairs in lane-private job slots and
-// copied after the sweep.  Persistent workgroups: tables are staged once per CU.
+// copied after the sweep, one lane per constant (the slots are handed out wave-wide, densely).
+// Persistent workgroups: tables are staged once per CU.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 // One step of the sweep (program without wide entries; piece_sweep2 in kx_sweeps.inc runs two chains
 // of them per lane): 6 VALU + 1 LDS read + 1 LDS write,
 //   a = row(t) + leaf;  e = lds[a];  leaf = e & 0x3FC;  o -= e.byte3;
 //   lds8[o | e<<31] = input byte t          (a step that copies nothing addresses out of range: dropped)
-//   if (e.bit23) { job slot <- o<<16 | a; slot += stride (saturating at the sink) }
+//   if (e.bit23) { job slot[wave count + rank among such lanes] <- o<<16 | a }   (clamped to the last slot)
 // The step in plain C++ for the other program shapes (one chain).  CONSTS: 0 = note a job, 1 = copy the
 // constant in place (short constants, or the second attempt of a lane whose job slots overflowed).
 template <int T_, bool WIDE, int CONSTS>
 __device__ __forceinline__ void emit_step_gen(const uint32_t (&bo)[BOW], const uint32_t (&w)[16], uint32_t& leaf, uint32_t& o,
-                                              uint32_t& jp, uint32_t js, uint32_t jl, const Lds& L, const DevTables& T) {
+                                              uint32_t& jb, uint32_t jlim, const Lds& L, const DevTables& T) {
   const uint32_t a = BO_GET_DEP(bo, T_, leaf) + leaf;
   const uint32_t e = L.w(a);
   leaf = E_LEAF4(e);
@@ -731,14 +734,17 @@ __device__ __forceinline__ void emit_step_gen(const uint32_t (&bo)[BOW], const u
   o -= dl;
   uint8_t* stg0 = const_cast<uint8_t*>(L.base);
   if (cp) stg0[o] = (uint8_t)BYTE_AT_DEP(w, T_, e);
-  if (E_HASCONST(e)) {
-    if constexpr (CONSTS == 0) {
-      *reinterpret_cast<uint32_t*>(stg0 + jp) = (o << 16) | a;
-      jp = jp + js < jl ? jp + js : jl;
-    } else {
-      const uint32_t cl = dl - cp, src = ent_off<WIDE>(e, a, L, T);
-      for (uint32_t i = 0; i < cl; ++i) stg0[o + cp + i] = L.pb(src + i);
+  const bool hc = E_HASCONST(e) != 0;
+  if constexpr (CONSTS == 0) {
+    const unsigned long long m = __ballot(hc);   // (inactive lanes vote 0)
+    if (hc) {
+      const uint32_t slot = jb + 4 * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      *reinterpret_cast<uint32_t*>(stg0 + (slot < jlim ? slot : jlim)) = (o << 16) | a;
     }
+    jb += 4 * (uint32_t)__popcll(m);
+  } else if (hc) {
+    const uint32_t cl = dl - cp, src = ent_off<WIDE>(e, a, L, T);
+    for (uint32_t i = 0; i < cl; ++i) stg0[o + cp + i] = L.pb(src + i);
   }
 }
 
@@ -797,7 +803,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       const bool fits = valid && lane >= first && (oend - abase) <= (uint64_t)stgb && len_hi != 0xFFFFu;
       const unsigned long long fm = __ballot(fits) >> first;
       uint32_t cnt = fm == ~0ull ? 64u - first : (uint32_t)__builtin_ctzll(~fm);   // leading run of fitting lanes
-      if (cnt > maxcnt) cnt = maxcnt;   // (the job slots are dealt out for at most maxcnt lanes per round)
+      if (cnt > maxcnt) cnt = maxcnt;   // (the job slots are dimensioned for maxcnt lanes per round)
       if (cnt == 0) {
         // a single piece larger than the staging area: its lane writes straight to global memory
         if (lane == first) {
@@ -824,51 +830,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       const uint32_t lastl = first + cnt - 1;
       const bool active = lane >= first && lane <= lastl;
       const uint32_t oe = stga + (uint32_t)(oend - abase);   // LDS address one past the piece's staged output
-      // job slots: jbytes/4 four-byte slots dealt out evenly to the round's lanes, slot k of a lane at
-      // jfirst + k*stride (bank-conflict free); the last slot is a sink that marks overflow
-      const uint32_t js = cnt * 4, jfirst = jarea + (lane - first) * 4, jlast = jfirst + ((jbytes / 4) / maxcnt - 1) * js;
-      uint32_t jp = jfirst;
-      // sweep: copied bytes into staging, constants into the lane's job slots (or in place)
+      // job slots: jbytes/4 four-byte slots per wave and round, handed out in the order the constants are met
+      const uint32_t jlim = __builtin_amdgcn_readfirstlane(jarea + jbytes - 4);
+      uint32_t jb = __builtin_amdgcn_readfirstlane(jarea);
+      // sweep: copied bytes into staging, constants into the job slots
       if (active) {
         if constexpr (!WIDE) {
-          piece_sweep2(bo, w, leaf_end4, oe, leaf_mid4, oe - len_hi, jp, js, jlast);
+          piece_sweep2(bo, w, leaf_end4, oe, leaf_mid4, oe - len_hi, jb, jlim);
         } else {
           uint32_t leaf = leaf_end4, o = oe;
           static_for<0, PIECE>([&](auto ic) {
             constexpr int t = PIECE - 1 - decltype(ic)::value;
-            emit_step_gen<t, WIDE, 0>(bo, w, leaf, o, jp, js, jlast, L, T);
+            emit_step_gen<t, WIDE, 0>(bo, w, leaf, o, jb, jlim, L, T);
           });
         }
       }
-      // a lane that ran out of job slots sweeps once more, copying its constants in place
-      const bool ovf = active && jp == jlast;
-      if (__any(ovf)) {
-        const unsigned long long om = __ballot(ovf);
-        if (lane == (uint32_t)__builtin_ctzll(om)) atomicAdd(&flags->emit_ovf, (uint32_t)__popcll(om));
-        if (ovf) {
+      jb = __builtin_amdgcn_readfirstlane(__shfl(jb, (int)first));   // (lane `first` took part in the sweep; lane 0 may not have)
+      uint32_t njobs = (jb - jarea) >> 2;
+      if (njobs > jbytes / 4) {
+        // more constants than slots (the last slot was overwritten): sweep once more, copying constants in place
+        if (lane == first) atomicAdd(&flags->emit_ovf, cnt);
+        if (active) {
           uint32_t leaf = leaf_end4, o = oe, jq = 0;
           static_for<0, PIECE>([&](auto ic) {
             constexpr int t = PIECE - 1 - decltype(ic)::value;
-            emit_step_gen<t, WIDE, 1>(bo, w, leaf, o, jq, 0u, 0u, L, T);
+            emit_step_gen<t, WIDE, 1>(bo, w, leaf, o, jq, 0u, L, T);
           });
-          jp = jfirst;
         }
+        njobs = 0;
       }
       wave_lds_fence();
-      // constants: every lane copies the ones its own piece noted
-      const uint32_t nj = active ? (jp - jfirst) / js : 0u;
-      for (uint32_t k = 0; __any(k < nj); ++k) {
-        if (k < nj) {
-          const uint32_t jb = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jfirst + k * js);
-          const uint32_t a = jb & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
-          const uint32_t d = stga + (((jb >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
-          uint8_t* dst = (uint8_t*)smem + d;
-          const uint8_t* sp = L.base + L.pool + src;
-          uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
-          for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
-          if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
-          if (l & 1) dst[i] = sp[i];
-        }
+      // constants: one lane per job
+      for (uint32_t j = lane; j < njobs; j += 64) {
+        const uint32_t jw = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jarea + 4 * j);
+        const uint32_t a = jw & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
+        const uint32_t d = stga + (((jw >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
+        uint8_t* dst = (uint8_t*)smem + d;
+        const uint8_t* sp = L.base + L.pool + src;
+        uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
+        for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
+        if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
+        if (l & 1) dst[i] = sp[i];
       }
       wave_lds_fence();
       // flush [gs, ge): partial head and tail windows bytewise, everything between as aligned 16 B
@@ -1412,16 +1414,17 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   int W = tab + 12 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 12 : tab + 8 * (size_t)EMIT_WAVE_LDS_MIN <= lds_cap ? 8 : 4;
   if (const char* ev = getenv("KX_EMIT_WAVES")) { int v = atoi(ev); if ((v == 4 || v == 8 || v == 12) && v <= W) W = v; }
   const size_t per_wave = ((lds_cap - tab) / W) & ~(size_t)255;
-  const uint32_t kmax = s->hflags.emit_kmax;   // most constants in one sampled piece (k_fixtail)
   // Rounds per iteration R = 1, 2, …: a round covers up to ceil(64/R) lanes, needs staging for their output
-  // (average piece output x 1.08) and kmax+2 job slots per lane
-  // (a lane whose write pointer reaches the last slot counts as overflowed); take the smallest R that fits the wave's LDS.
+  // (average piece output x 1.08) and job slots for their constants (k_fixtail's sample: average per piece x 1.25
+  // + 1.5, at most the sampled maximum + 1); take the smallest R that fits the wave's LDS.
   const double olen = 64.0 * (double)s->out_len / (double)(s->n ? s->n : 1);
-  const uint32_t kslots = (kmax < 63 ? kmax : 63) + 2;
+  const uint32_t kmax = s->hflags.emit_kmax < 64 ? s->hflags.emit_kmax : 64;
+  double kper = s->hflags.emit_kn ? 1.25 * (double)s->hflags.emit_ksum / (double)s->hflags.emit_kn + 1.5 : (double)kmax + 1;
+  if (kper > kmax + 1) kper = kmax + 1;
   size_t stgb = 0, jbytes = 0; uint32_t maxcnt = 64;
   for (uint32_t R = 1; R <= 64; ++R) {
     const uint32_t c = (64 + R - 1) / R;
-    size_t st = (((size_t)(c * olen * 1.08) + 64) + 255) & ~(size_t)255, jb = ((size_t)c * kslots * 4 + 255) & ~(size_t)255;
+    size_t st = (((size_t)(c * olen * 1.08) + 64) + 255) & ~(size_t)255, jb = ((size_t)(c * kper + 16) * 4 + 255) & ~(size_t)255;
     if (st < 1024) st = 1024;
     if (st + 16 + jb <= per_wave || c == 1) {
       maxcnt = c; jbytes = jb; stgb = per_wave - 16 - jb;   // the rest goes to staging (bigger pieces fit, fewer oversize ones)
@@ -1444,11 +1447,12 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   if (timing) HIPCHECK(hipEventRecord(p->ev[1], s->stream));
   HIPCHECK(hipGetLastError());
   uint32_t ovf = 0;
-  HIPCHECK(hipMemcpyAsync(&ovf, &s->flags->emit_ovf, 4, hipMemcpyDeviceToHost, s->stream));
+  const bool debug = getenv("KX_DEBUG") != nullptr;
+  if (timing || debug) HIPCHECK(hipMemcpyAsync(&ovf, &s->flags->emit_ovf, 4, hipMemcpyDeviceToHost, s->stream));
   HIPCHECK(hipStreamSynchronize(s->stream));
   if (timing) s->stats.kernel_ms[KX_K_EMIT] = evMs(p->ev[0], p->ev[1]);
   s->stats.emit_overflow_pieces = ovf;
-  if (getenv("KX_DEBUG")) fprintf(stderr, "[kx] emit: W=%d stg=%zu jobs=%zu maxcnt=%u kmax=%u olen=%.1f overflow=%u of %llu pieces\n", W, stgb, jbytes, maxcnt, kmax, olen, ovf, (unsigned long long)npieces);
+  if (debug) fprintf(stderr, "[kx] emit: W=%d stg=%zu jobs=%zu maxcnt=%u kmax=%u kavg=%.2f olen=%.1f overflow=%u of %llu pieces\n", W, stgb, jbytes, maxcnt, kmax, s->hflags.emit_kn ? (double)s->hflags.emit_ksum / s->hflags.emit_kn : -1.0, olen, ovf, (unsigned long long)npieces);
   return 0;
 }
 

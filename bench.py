@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -44,8 +45,9 @@ def cpu_baseline(program, base, sample_bytes):
         best = None
         for _ in range(2):
             with open(path, "rb") as fin, open(os.devnull, "wb") as devnull:
-                r = subprocess.run([exe, "-t"], stdin=fin, stdout=devnull, stderr=subprocess.PIPE, check=True)
-            ms = int(r.stderr.decode().strip().split(":")[-1])
+                env = {k: v for k, v in os.environ.items() if not (k.startswith("ROCP") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB"))}
+                r = subprocess.run([exe, "-t"], stdin=fin, stdout=devnull, stderr=subprocess.PIPE, check=True, env=env)
+            ms = int(re.findall(r"\(ms\):\s*(\d+)", r.stderr.decode())[-1])
             best = ms if best is None else min(best, ms)
         nbytes = k * len(base)
         return {"value": round(nbytes / 1e9 / (best / 1e3), 4), "unit": "GB/s", "cores": 1, "kind": kind,
@@ -179,7 +181,8 @@ def main():
         ksum = sum(kern.values())
         traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            import glob
+            tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))[-1]))   # latest PMC passes
             if a.program == "apache_log" and abs(tj["input_bytes"] - n_local) < (1 << 20):
                 traffic = tj["per_launch"]["k_" + dom]["total"]
         except Exception:

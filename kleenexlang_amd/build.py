@@ -59,6 +59,10 @@ def build_engine(force=False):
     os.makedirs(OUT, exist_ok=True)
     deps = _deps([os.path.join(CSRC, "engine"), os.path.join(ROOT, "include")])
     lib = os.path.join(OUT, "libkxhip.so")
+    gen, inc = os.path.join(CSRC, "engine", "gen_sweeps.py"), os.path.join(CSRC, "engine", "kx_sweeps.inc")
+    if not os.path.exists(inc) or os.path.getmtime(gen) > os.path.getmtime(inc):   # hand-scheduled sweeps (generated text)
+        with open(inc, "w") as f:
+            subprocess.check_call([sys.executable, gen], stdout=f)
     if force or _newer(lib, deps):
         if not os.path.exists(HIPCC):
             raise RuntimeError("hipcc not found at %s" % HIPCC)

@@ -65,6 +65,8 @@ typedef struct kx_config {
   uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; 0 = by input size (4-16 KiB) */
   uint32_t block_threads;  /* workgroup size (power of two); default 512        */
   uint32_t collect_timing; /* record per-kernel HIP events into kx_stats        */
+  uint32_t pad;
+  uint64_t window_bytes;   /* kx_run_fd: input bytes resident at a time; 0 = 4 GiB (env KX_WINDOW_BYTES overrides) */
 } kx_config;
 
 int kx_load(const void* blob, size_t blob_len, kx_program** prog);

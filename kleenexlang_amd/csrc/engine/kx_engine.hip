@@ -927,19 +927,18 @@ struct Arena {  // grow-only device workspace, reused across runs
 
 struct kx_program {
   std::vector<Stage> stages;
-  kx_config cfg{0, 512, 0};
-  Arena arena;                     // shard workspace
+  kx_config cfg{0, 512, 0, 0, 0};
+  std::vector<Arena*> arenas;      // shard workspaces (grow-only), handed out to open shards and taken back
   void* stagebuf[2] = {nullptr, nullptr};   // ping-pong buffers between pipeline stages
   size_t stagecap[2] = {0, 0};
   hipEvent_t ev[KX_NKERNELS + 1] = {};
   bool have_events = false;
-  kx_shard* live = nullptr;
   int ncu = 256;
 
 };
 
 struct kx_shard {
-  kx_program* prog; Stage* st; uint32_t stage;
+  kx_program* prog; Stage* st; uint32_t stage; Arena* arena = nullptr;
   const uint8_t* in; uint64_t n; int is_first, is_last; hipStream_t stream;
   uint64_t seg; uint32_t nseg, nblk, Lc, ngroups;
   // workspace
@@ -1166,7 +1165,7 @@ int kx_load(const void* blob, size_t blob_len, kx_program** prog) {
 void kx_free(kx_program* p) {
   if (!p) return;
   for (auto& s : p->stages) if (s.d_all) (void)hipFree(s.d_all);
-  if (p->arena.base) (void)hipFree(p->arena.base);
+  for (Arena* a : p->arenas) { if (a->base) (void)hipFree(a->base); delete a; }
   for (int i = 0; i < 2; ++i) if (p->stagebuf[i]) (void)hipFree(p->stagebuf[i]);
   if (p->have_events) for (auto& e : p->ev) (void)hipEventDestroy(e);
   delete p;
@@ -1189,7 +1188,6 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
                    void* stream, kx_shard** out) {
   if (!p || !out || stage >= p->stages.size()) return setErr(KX_E_ARG, "bad program/stage");
   if (n && (!d_in || ((uintptr_t)d_in & 15))) return setErr(KX_E_ARG, "input must be 16-byte aligned");
-  if (p->live) return setErr(KX_E_ARG, "a shard is already open on this program");
   auto* s = new kx_shard;
   s->prog = p; s->st = &p->stages[stage]; s->stage = stage;
   s->in = (const uint8_t*)d_in; s->n = n; s->is_first = is_first; s->is_last = is_last; s->stream = (hipStream_t)stream;
@@ -1201,12 +1199,14 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   const uint32_t bt = p->cfg.block_threads;
   s->ngroups = (s->nblk + bt - 1) / bt;
   // workspace layout
-  Arena& A = p->arena;
+  if (p->arenas.empty()) p->arenas.push_back(new Arena);
+  s->arena = p->arenas.back(); p->arenas.pop_back();
+  Arena& A = *s->arena;
   size_t need = 4096 + (size_t)s->nseg * (8 + 2) + (n / HALF + 32) * 2 + sizeof(Flags) +
                 (size_t)s->nblk * ((size_t)s->Lc * 5 + 3 + 4 + 8 + 2 + 4) + (size_t)s->ngroups * 16 + KX_MAX_LEAVES + 64 +
                 (n / PIECE + 16) * 8 + 256 * 32;
   int rc = A.reserve(need);
-  if (rc) { delete s; return rc; }
+  if (rc) { p->arenas.push_back(s->arena); delete s; return rc; }
   A.reset();
   s->seg_pos = A.take<uint64_t>(s->nseg); s->seg_state = A.take<uint16_t>(s->nseg);
   s->chk = A.take<uint16_t>(n / HALF + 32); s->flags = A.take<Flags>(1);
@@ -1218,11 +1218,10 @@ int kx_shard_begin(kx_program* p, uint32_t stage, const void* d_in, size_t n, in
   s->prec = A.take<PieceRec>(n / PIECE + 16);
   s->merge_piece = A.take<uint16_t>(s->nblk); s->ctot = A.take<uint32_t>(s->nblk);
   if (!p->have_events) {
-    for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { delete s; return setErr(KX_E_HIP, "hipEventCreate failed"); }
+    for (auto& e : p->ev) if (hipEventCreate(&e) != hipSuccess) { p->arenas.push_back(s->arena); delete s; return setErr(KX_E_HIP, "hipEventCreate failed"); }
     p->have_events = true;
   }
   s->stats.in_bytes = n;
-  p->live = s;
   *out = s;
   return 0;
 }
@@ -1464,7 +1463,7 @@ void kx_shard_stats(kx_shard* s, kx_stats* st) {
 
 void kx_shard_end(kx_shard* s) {
   if (!s) return;
-  if (s->prog->live == s) s->prog->live = nullptr;
+  if (s->arena) s->prog->arenas.push_back(s->arena);
   delete s;
 }
 
@@ -1555,89 +1554,198 @@ void kx_host_free(void* p) { free(p); }
 // stdin → pinned host → HBM → engine → pinned host → stdout.  Reads and H2D copies overlap (two
 // pinned staging buffers), and so do D2H copies and writes.  The whole input is resident in HBM
 // while the engine runs (SURVEY §8f rank 1 asks for windowed streaming on top; not built yet).
-int kx_run_fd(kx_program* p, int in_fd, int out_fd, kx_stats* stats) {
-  if (!p) return setErr(KX_E_ARG, "null argument");
-  const size_t CH = 64u << 20;
-  char* pin[2] = {nullptr, nullptr};
-  hipEvent_t ev[2];
+// ------------------------------------------------------------------ streaming: stdin → HBM → stdout
+// The input is processed in windows (default 4 GiB; everything up to that is one window).  A window is one
+// shard of the sharded protocol: its start state is the previous window's end state; its end leaf is the
+// next window's start leaf, so a window's output is placed once the next window's backward summary is known
+// (immediately when that summary does not depend on the end leaf — "constant" — which is the rule; otherwise
+// windows queue up until one is, or until the last).  Multi-stage programs chain such streams: the output
+// windows of stage i are the input windows of stage i+1.  Reads overlap the host→device copies and
+// device→host copies overlap the writes through pinned staging buffers.
+namespace {
+
+struct FdStream {
+  kx_program* p = nullptr; int in_fd = -1, out_fd = -1;
+  size_t CH = 64u << 20, window = 0;
+  char* pin[4] = {nullptr, nullptr, nullptr, nullptr};   // 0,1: input staging; 2,3: output staging
+  hipEvent_t ev[4] = {}; bool have_ev = false;
   hipStream_t cs = nullptr;
-  char* d_in = nullptr; size_t dcap = 0, n = 0;
-  void* d_out = nullptr;
-  int rc = 0;
-  auto cleanup = [&]() {
-    for (int k = 0; k < 2; ++k) { if (pin[k]) (void)hipHostFree(pin[k]); }
-    if (cs) { (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]); (void)hipStreamDestroy(cs); }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
-  };
-#define KX_FD_CHECK(expr) do { if ((expr) != hipSuccess) { cleanup(); return setErr(KX_E_HIP, #expr " failed"); } } while (0)
-  KX_FD_CHECK(hipStreamCreate(&cs));
-  KX_FD_CHECK(hipEventCreate(&ev[0])); KX_FD_CHECK(hipEventCreate(&ev[1]));
-  KX_FD_CHECK(hipHostMalloc((void**)&pin[0], CH, hipHostMallocDefault));
-  KX_FD_CHECK(hipHostMalloc((void**)&pin[1], CH, hipHostMallocDefault));
-  struct stat stt;
-  if (fstat(in_fd, &stt) == 0 && S_ISREG(stt.st_mode)) {   // regular file: size known up front
-    off_t pos = lseek(in_fd, 0, SEEK_CUR);
-    if (pos >= 0 && stt.st_size > pos) dcap = (size_t)(stt.st_size - pos) + 16;
+  int rk = 0; size_t carry = 0; bool eof = false;          // reader: chunk read ahead in pin[rk]
+  struct Win { kx_shard* sh; char* d_in; size_t n; kx_bwd_summary bs; };
+  struct StageQ { std::vector<Win> pend; uint32_t end_state = 0; bool first = true; uint64_t consumed = 0; };
+  std::vector<StageQ> q;
+  kx_stats total{};
+
+  ~FdStream() {
+    for (auto& sq : q) for (auto& w : sq.pend) { if (w.sh) kx_shard_end(w.sh); if (w.d_in) (void)hipFree(w.d_in); }
+    for (auto& b : pin) if (b) (void)hipHostFree(b);
+    if (have_ev) for (auto& e : ev) (void)hipEventDestroy(e);
+    if (cs) (void)hipStreamDestroy(cs);
   }
-  if (dcap == 0) dcap = 4 * CH;
-  KX_FD_CHECK(hipMalloc((void**)&d_in, dcap));
-  for (int k = 0;; k ^= 1) {
-    KX_FD_CHECK(hipEventSynchronize(ev[k]));   // the previous copy out of this staging buffer is done
-    size_t got = 0;
-    while (got < CH) {
-      ssize_t r = read(in_fd, pin[k] + got, CH - got);
-      if (r < 0) { if (errno == EINTR) continue; cleanup(); return setErr(KX_E_IO, "read failed"); }
+  int init() {
+    HIPCHECK(hipStreamCreate(&cs));
+    for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
+    have_ev = true;
+    for (auto& b : pin) HIPCHECK(hipHostMalloc((void**)&b, CH, hipHostMallocDefault));
+    q.resize(p->stages.size());
+    total.fail_pos = NOFAIL;
+    return 0;
+  }
+  int readChunk(char* dst, size_t* got) {
+    size_t g = 0;
+    while (g < CH) {
+      ssize_t r = read(in_fd, dst + g, CH - g);
+      if (r < 0) { if (errno == EINTR) continue; return setErr(KX_E_IO, "read failed"); }
       if (r == 0) break;
-      got += (size_t)r;
+      g += (size_t)r;
     }
-    if (got == 0) break;
-    if (n + got > dcap) {   // pipe of unknown length: grow geometrically
-      size_t ncap = dcap * 2 > n + got ? dcap * 2 : n + got + CH;
-      char* nd = nullptr;
-      KX_FD_CHECK(hipMalloc((void**)&nd, ncap));
-      KX_FD_CHECK(hipStreamSynchronize(cs));
-      KX_FD_CHECK(hipMemcpy(nd, d_in, n, hipMemcpyDeviceToDevice));
-      (void)hipFree(d_in); d_in = nd; dcap = ncap;
-    }
-    KX_FD_CHECK(hipMemcpyAsync(d_in + n, pin[k], got, hipMemcpyHostToDevice, cs));
-    KX_FD_CHECK(hipEventRecord(ev[k], cs));
-    n += got;
-    if (got < CH) break;
+    *got = g;
+    return 0;
   }
-  KX_FD_CHECK(hipStreamSynchronize(cs));
-  size_t ol = 0;
-  rc = runPipeline(p, d_in, n, nullptr, 0, true, &d_out, &ol, stats, nullptr);
-  if (rc == 0) {
-    size_t done = 0, issued = 0;
-    size_t clen[2] = {0, 0};
+  // next window of the input: device buffer (owned by the caller afterwards), its length, whether it is the last
+  int nextWindow(char** d_out, size_t* n_out, bool* last) {
+    size_t cap = window, n = 0;
+    struct stat stt;
+    if (carry == 0 && !eof && fstat(in_fd, &stt) == 0 && S_ISREG(stt.st_mode)) {   // regular file: do not over-allocate
+      off_t pos = lseek(in_fd, 0, SEEK_CUR);
+      if (pos >= 0 && (size_t)(stt.st_size - pos) + CH < cap) cap = ((size_t)(stt.st_size > pos ? stt.st_size - pos : 0) / CH + 1) * CH;
+    }
+    char* d = nullptr;
+    HIPCHECK(hipMalloc((void**)&d, cap + 16));
+    while (n < cap && !eof) {
+      size_t got = carry;
+      if (!got) {
+        if (hipEventSynchronize(ev[rk]) != hipSuccess) { (void)hipFree(d); return setErr(KX_E_HIP, "hipEventSynchronize failed"); }
+        int rc = readChunk(pin[rk], &got);
+        if (rc) { (void)hipFree(d); return rc; }
+      }
+      carry = 0;
+      if (got) {
+        if (hipMemcpyAsync(d + n, pin[rk], got, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(ev[rk], cs) != hipSuccess) {
+          (void)hipFree(d); return setErr(KX_E_HIP, "host to device copy failed");
+        }
+        n += got; rk ^= 1;
+      }
+      if (got < CH) eof = true;
+    }
+    if (!eof) {   // the window is full: read one chunk ahead to learn whether anything follows
+      if (hipEventSynchronize(ev[rk]) != hipSuccess) { (void)hipFree(d); return setErr(KX_E_HIP, "hipEventSynchronize failed"); }
+      int rc = readChunk(pin[rk], &carry);
+      if (rc) { (void)hipFree(d); return rc; }
+      if (carry == 0) eof = true;
+    }
+    if (hipStreamSynchronize(cs) != hipSuccess) { (void)hipFree(d); return setErr(KX_E_HIP, "hipStreamSynchronize failed"); }
+    *d_out = d; *n_out = n; *last = eof && carry == 0;
+    return 0;
+  }
+  int writeOut(const char* d, size_t ol) {
+    size_t done = 0, issued = 0, clen[2] = {0, 0};
     int k = 0;
     if (issued < ol) {
       clen[0] = ol - issued < CH ? ol - issued : CH;
-      KX_FD_CHECK(hipMemcpyAsync(pin[0], (char*)d_out + issued, clen[0], hipMemcpyDeviceToHost, cs));
-      KX_FD_CHECK(hipEventRecord(ev[0], cs));
+      HIPCHECK(hipMemcpyAsync(pin[2], d + issued, clen[0], hipMemcpyDeviceToHost, cs));
+      HIPCHECK(hipEventRecord(ev[2], cs));
       issued += clen[0];
     }
     while (done < ol) {
       if (issued < ol) {   // next chunk flies while this one is written
         clen[k ^ 1] = ol - issued < CH ? ol - issued : CH;
-        KX_FD_CHECK(hipMemcpyAsync(pin[k ^ 1], (char*)d_out + issued, clen[k ^ 1], hipMemcpyDeviceToHost, cs));
-        KX_FD_CHECK(hipEventRecord(ev[k ^ 1], cs));
+        HIPCHECK(hipMemcpyAsync(pin[2 + (k ^ 1)], d + issued, clen[k ^ 1], hipMemcpyDeviceToHost, cs));
+        HIPCHECK(hipEventRecord(ev[2 + (k ^ 1)], cs));
         issued += clen[k ^ 1];
       }
-      KX_FD_CHECK(hipEventSynchronize(ev[k]));
+      HIPCHECK(hipEventSynchronize(ev[2 + k]));
       size_t w = 0;
       while (w < clen[k]) {
-        ssize_t r = write(out_fd, pin[k] + w, clen[k] - w);
-        if (r < 0) { if (errno == EINTR) continue; cleanup(); return setErr(KX_E_IO, "write failed"); }
+        ssize_t r = write(out_fd, pin[2 + k] + w, clen[k] - w);
+        if (r < 0) { if (errno == EINTR) continue; return setErr(KX_E_IO, "write failed"); }
         w += (size_t)r;
       }
       done += clen[k];
       k ^= 1;
     }
+    return 0;
   }
-#undef KX_FD_CHECK
-  cleanup();
+  // window `d` (ownership taken) enters stage `st`
+  int push(uint32_t st, char* d, size_t n, bool last) {
+    StageQ& sq = q[st];
+    Win w{nullptr, d, n, {}};
+    int rc = kx_shard_begin(p, st, d, n, sq.first ? 1 : 0, last ? 1 : 0, nullptr, &w.sh);
+    if (rc) { (void)hipFree(d); return rc; }
+    sq.pend.push_back(w);
+    Win& W = sq.pend.back();
+    kx_fwd_summary fs;
+    rc = kx_shard_forward(W.sh, &fs);
+    if (!rc) rc = kx_shard_fix_head(W.sh, sq.first ? 0 : sq.end_state, &fs);
+    if (rc) return rc;
+    if (fs.fail_pos != NOFAIL) { total.fail_pos = sq.consumed + fs.fail_pos; total.fail_stage = st; return KX_MATCH_ERROR; }
+    sq.end_state = fs.end_state; sq.first = false; sq.consumed += n;
+    rc = kx_shard_backward(W.sh, &W.bs);
+    if (rc) return rc;
+    accumulate(W.sh);
+    // which queued windows now know the leaf they end in?
+    size_t nres = 0;
+    std::vector<uint32_t> ends(sq.pend.size(), 0);
+    if (last) nres = sq.pend.size();                     // the last window resolves its own end leaf from the final state
+    else if (W.bs.constant) nres = sq.pend.size() - 1;   // everything before this window
+    if (nres == 0) {
+      if (sq.pend.size() > 64) return setErr(KX_E_ARG, "the program's output stays undetermined across more than 64 windows; use a larger window");
+      return 0;
+    }
+    for (size_t j = nres; j-- > 0;) {
+      if (j + 1 < sq.pend.size()) { const Win& nx = sq.pend[j + 1]; ends[j] = nx.bs.start_leaf[nx.bs.constant ? 0 : ends[j + 1]]; }
+    }
+    for (size_t j = 0; j < nres; ++j) {
+      Win& R = sq.pend[j];
+      const bool rlast = last && j + 1 == sq.pend.size();
+      uint64_t ol = 0;
+      rc = kx_shard_resolve(R.sh, ends[j], &ol);
+      if (rc) return rc;
+      char* dout = nullptr;
+      HIPCHECK(hipMalloc((void**)&dout, (size_t)ol + 16));
+      rc = kx_shard_emit(R.sh, dout, (size_t)ol);
+      accumulate(R.sh);
+      kx_shard_end(R.sh); R.sh = nullptr;
+      (void)hipFree(R.d_in); R.d_in = nullptr;
+      if (rc) { (void)hipFree(dout); return rc; }
+      if (st + 1 < q.size()) {
+        if (ol || rlast) rc = push(st + 1, dout, (size_t)ol, rlast);   // (push takes the buffer)
+        else (void)hipFree(dout);
+      } else {
+        total.out_bytes += ol;
+        rc = writeOut(dout, (size_t)ol);
+        (void)hipFree(dout);
+      }
+      if (rc) return rc;
+    }
+    sq.pend.erase(sq.pend.begin(), sq.pend.begin() + nres);
+    return 0;
+  }
+  void accumulate(kx_shard* sh) {
+    kx_stats ss; kx_shard_stats(sh, &ss);
+    total.unsynced_segments = total.unsynced_segments > ss.unsynced_segments ? total.unsynced_segments : ss.unsynced_segments;
+  }
+};
+
+}  // namespace
+
+extern "C" int kx_run_fd(kx_program* p, int in_fd, int out_fd, kx_stats* stats) {
+  if (!p) return setErr(KX_E_ARG, "null argument");
+  FdStream fsr;
+  fsr.p = p; fsr.in_fd = in_fd; fsr.out_fd = out_fd;
+  size_t window = p->cfg.window_bytes ? p->cfg.window_bytes : (size_t)4 << 30;
+  if (const char* ev = getenv("KX_WINDOW_BYTES")) { long long v = atoll(ev); if (v > 0) window = (size_t)v; }
+  if (window < 4096) window = 4096;
+  if (fsr.CH > window) fsr.CH = (window + 4095) & ~(size_t)4095;
+  fsr.window = (window + fsr.CH - 1) / fsr.CH * fsr.CH;
+  int rc = fsr.init();
+  bool last = false;
+  while (!rc && !last) {
+    char* d = nullptr; size_t n = 0;
+    rc = fsr.nextWindow(&d, &n, &last);
+    if (!rc) { fsr.total.in_bytes += n; rc = fsr.push(0, d, n, last); }
+  }
+  if (stats) *stats = fsr.total;
   return rc;
 }
 

@@ -55,7 +55,7 @@ class KxStats(ctypes.Structure):
 
 class KxConfig(ctypes.Structure):
     _fields_ = [("segment_bytes", ctypes.c_uint32), ("block_threads", ctypes.c_uint32),
-                ("collect_timing", ctypes.c_uint32)]
+                ("collect_timing", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
 
 
 class KxFwdSummary(ctypes.Structure):
@@ -203,14 +203,14 @@ def compile_file(path, opt=3):
 class Program:
     """A compiled Kleenex program loaded on the current HIP device."""
 
-    def __init__(self, blob, segment_bytes=0, block_threads=0, collect_timing=False):
+    def __init__(self, blob, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0):
         self._lib = load_engine()
         self._h = ctypes.c_void_p()
         self._blob = bytes(blob)
         rc = self._lib.kx_load(self._blob, len(self._blob), ctypes.byref(self._h))
         if rc:
             raise EngineError(self._err())
-        self.configure(segment_bytes, block_threads, collect_timing)
+        self.configure(segment_bytes, block_threads, collect_timing, window_bytes)
         self.last_stats = None
 
     @classmethod
@@ -224,8 +224,8 @@ class Program:
     def _err(self):
         return self._lib.kx_last_error().decode("utf-8", "replace")
 
-    def configure(self, segment_bytes=0, block_threads=0, collect_timing=False):
-        cfg = KxConfig(segment_bytes, block_threads, 1 if collect_timing else 0)
+    def configure(self, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0):
+        cfg = KxConfig(segment_bytes, block_threads, 1 if collect_timing else 0, 0, window_bytes)
         if self._lib.kx_set_config(self._h, ctypes.byref(cfg)):
             raise EngineError(self._err())
 

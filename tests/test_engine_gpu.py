@@ -226,3 +226,43 @@ def test_produced_binary_stdin_stdout_contract(tmp_path):
     assert b"time (ms): " in r.stderr
     r = subprocess.run([str(exe)], input=data[:1000], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and r.stdout == b"" and r.stderr.endswith(b"Match error at input symbol 1000!\n")
+
+
+def test_produced_binary_streams_inputs_in_windows(tmp_path):
+    """kx_run_fd keeps a bounded window of the input in HBM: every window is one shard of the sharded
+    protocol (start state from the previous window, end leaf from the next).  Windows far smaller than the
+    input, through a pipe and from a regular file, single- and multi-stage, accepting and rejecting."""
+    import subprocess
+    from kleenexlang_amd import build, program_path
+    kexc = os.path.join(build.OUT, "kexc")
+    two_stage = tmp_path / "two.kex"
+    two_stage.write_text('start: commas >> brackets\n'
+                         'commas := (num /\\n/)*\nnum := digit{1,3} ("," digit{3})*\ndigit := /[0-9]/\n'
+                         'brackets := (/[0-9]+/ "<" | /,/ ">" | /\\n/)*\n')
+    cases = [("apache_log", program_path("apache_log"), workloads.generate("apache_log", 700000, 9)),
+             ("thousand_sep", program_path("thousand_sep"), workloads.generate(workloads.PROGRAM_INPUT["thousand_sep"], 300000, 3)),
+             ("two_stage", str(two_stage), workloads.generate("numbers", 200000, 4))]
+    for name, path, data in cases:
+        exe = tmp_path / name
+        assert subprocess.run([kexc, "compile", "--quiet", path, "--out", str(exe)]).returncode == 0
+        want = oracle.run(blob_of(open(path).read()), data)
+        infile = tmp_path / (name + ".in")
+        infile.write_bytes(data)
+        for window in (4096, 65536, 262144, 1 << 30):
+            env = dict(os.environ, KX_WINDOW_BYTES=str(window))
+            r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)   # pipe
+            assert r.returncode == 0 and r.stdout == want, (name, window, r.stderr[-200:])
+            with open(infile, "rb") as f:                                                                          # regular file
+                r = subprocess.run([str(exe)], stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert r.returncode == 0 and r.stdout == want, (name, window, "file")
+        # rejection in a later window: the symbol count is global, and no output beyond the accepted windows appears
+        bad = data[:150000] + b"\x00" + data[150000:]
+        try:
+            oracle.run(blob_of(open(path).read()), bad)
+            pos = None
+        except oracle.OracleMatchError as e:
+            pos = e.pos
+        if pos is not None:
+            r = subprocess.run([str(exe)], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KX_WINDOW_BYTES="65536"))
+            assert r.returncode == 1 and r.stderr.endswith(b"Match error at input symbol %d!\n" % pos), (name, r.stderr[-100:])
+            assert want.startswith(r.stdout[:len(r.stdout)]) or name == "two_stage"

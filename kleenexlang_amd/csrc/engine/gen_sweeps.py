@@ -17,6 +17,10 @@ before doing the bookkeeping of the current step.
       31..0 from (leafB, oB); see the step description in kx_engine.hip (k_emit).  jb (SGPR, in/out) is
       the LDS address of the wave's next free job slot, jlim that of the last slot.
 
+  piece_forward1 / piece_run1 / piece_walk1
+      one-chain forms for k_backlen (whose two input pieces per trip leave no room for two chains) and
+      k_forward: forward with / without recording the back rows, and the measuring backward walk.
+
 The file is generated (python gen_sweeps.py > kx_sweeps.inc) and committed; build.py regenerates it
 when this script is newer.
 """
@@ -107,6 +111,55 @@ def sweep2():
     return L
 
 
+def fwd1(pack):
+    """one chain over the 64 bytes of a piece from handle h; pack=True also records the back rows (bo)"""
+    L = []
+    ap = L.append
+    def cls_issue(tt):
+        ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (tt >> 2, SD, tt & 3))
+        ap("ds_read_u8 %%[c%d], %%[x]" % (tt % 3))
+    for tt in (0, 1, 2):
+        cls_issue(tt)
+    ap("s_waitcnt lgkmcnt(2)")
+    ap("v_add_u32 %[x], %[h], %[c0]")
+    ap("ds_read_b32 %[e0], %[x]")
+    for j in range(64):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 3 < 64:
+            cls_issue(j + 3)
+        ap("s_waitcnt lgkmcnt(%d)" % (1 if j + 3 < 64 else 0))
+        if j + 1 < 64:
+            ap("v_add_u32_sdwa %%[x], %%[e%d], %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (cur, (j + 1) % 3, SD))
+            ap("ds_read_b32 %%[e%d], %%[x]" % nxt)
+        if pack:
+            if j & 1:
+                ap("v_and_or_b32 %%[bo%d], %%[e%d], %%[hm], %%[bo%d]" % (j >> 1, cur, j >> 1))
+            else:
+                ap("v_lshrrev_b32 %%[bo%d], 16, %%[e%d]" % (j >> 1, cur))
+        else:
+            if j == 31:
+                ap("v_and_b32 %%[mid], 0xffff, %%[e%d]" % cur)
+            if j == 63:
+                ap("v_and_b32 %%[h], 0xffff, %%[e%d]" % cur)
+    return L
+
+
+def walk1():
+    """backward walk that only measures: leaf chain + appended-byte sum, with the state in the middle of the piece"""
+    L = []
+    ap = L.append
+    for t in range(63, -1, -1):
+        ap("v_add_u32_sdwa %%[a], %%[bo%d], %%[leaf] %s src0_sel:WORD_%d src1_sel:DWORD" % (t >> 1, SD, t & 1))
+        ap("ds_read_b32 %[e], %[a]")
+        ap("s_waitcnt lgkmcnt(0)")
+        ap("v_and_b32 %[leaf], 0x3fc, %[e]")
+        ap("v_add_u32_sdwa %%[sum], %%[sum], %%[e] %s src0_sel:DWORD src1_sel:BYTE_3" % SD)
+        if t == 32:
+            ap("v_mov_b32 %[lmid], %[leaf]")
+            ap("v_mov_b32 %[shi], %[sum]")
+    return L
+
+
 def emit_fn(out, name, sig, decl, lines, outs, ins, clob):
     out.write("__device__ __forceinline__ void %s(%s) {\n" % (name, sig))
     if decl:
@@ -141,5 +194,31 @@ def main():
             '"vcc", "scc", "memory"')
 
 
+def main2(out):
+    tmp = ["e0", "e1", "c0", "c1", "c2", "x"]
+    emit_fn(out, "piece_forward1",
+            "const uint32_t (&w)[16], uint32_t h, uint32_t himask, uint32_t (&bo)[32]",
+            "uint32_t " + ", ".join(tmp) + ";",
+            fwd1(True),
+            ['[bo%d] "=&v"(bo[%d])' % (i, i) for i in range(32)] + ['[%s] "=&v"(%s)' % (t, t) for t in tmp],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[h] "v"(h)', '[hm] "s"(himask)'],
+            '"memory"')
+    emit_fn(out, "piece_run1",
+            "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid",
+            "uint32_t " + ", ".join(tmp) + ";",
+            fwd1(False),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[h] "+v"(h)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
+            '"memory"')
+    emit_fn(out, "piece_walk1",
+            "const uint32_t (&bo)[32], uint32_t& leaf, uint32_t& sum, uint32_t& lmid, uint32_t& shi",
+            "uint32_t a, e;",
+            walk1(),
+            ['[a] "=&v"(a)', '[e] "=&v"(e)', '[lmid] "=&v"(lmid)', '[shi] "=&v"(shi)', '[leaf] "+v"(leaf)', '[sum] "+v"(sum)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)],
+            '"memory"')
+
+
 if __name__ == "__main__":
     main()
+    main2(sys.stdout)

@@ -217,6 +217,9 @@ __global__ void k_sync(const uint8_t* __restrict__ in, uint64_t n, uint64_t seg,
   else { seg_pos[k] = UNSYNC; seg_state[k] = 0; atomicAdd(&flags->unsynced, 1u); }
 }
 
+// the hand-scheduled per-piece instruction sequences (generated text, see gen_sweeps.py)
+#include "kx_sweeps.inc"
+
 // ---------------------------------------------------------------------------- k_forward
 // The absorbing dead handle stands for "no transition", so the hot loop has no failure branch; the
 // exact position is recovered by re-running the 64-byte piece in which the run died.
@@ -281,6 +284,7 @@ __global__ void k_forward(const uint8_t* __restrict__ in, uint64_t n, uint32_t n
   }
   // 64 chained transitions over one piece held in registers; `mid` = the state after the first 32
   auto run_piece = [&](const uint32_t (&w)[16], uint32_t hh, uint32_t& mid) {
+    if constexpr (!GENERAL) { piece_run1(w, hh, mid); return hh; }
     uint32_t c[8], cn[8];
     static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; c[i] = L.c4(BYTE_AT_DEP(w, i, hh)); });
     static_for<0, PIECE / 8>([&](auto gc) {
@@ -392,8 +396,6 @@ constexpr int BOW = PIECE / 2;
 __device__ __forceinline__ void bo_set(uint32_t (&bo)[BOW], int t, uint32_t v) {
   bo[t >> 1] = (t & 1) ? ((bo[t >> 1] & 0xFFFFu) | (v << 16)) : ((bo[t >> 1] & 0xFFFF0000u) | v);
 }
-// piece_forward2 / piece_sweep2: the hand-scheduled two-chain sequences (generated text, see gen_sweeps.py)
-#include "kx_sweeps.inc"
 // one chain, scheduled by the compiler: k_backlen keeps two pieces of input in registers and has no room
 // for the two-chain sequence's 62 simultaneously live registers
 __device__ __forceinline__ void piece_forward(const uint32_t (&w)[16], uint32_t h, const Lds& L, uint32_t (&bo)[BOW]) {
@@ -518,12 +520,14 @@ __global__ void k_backlen(const uint8_t* __restrict__ in, uint64_t n, uint64_t b
           }
           hA = reinterpret_cast<const uint16_t*>(lrec + 4)[p & 7];
         } else hA = chk[2 * (piece0 + p)];
-        piece_forward(w, hA, L, bo);
+        if constexpr (WIDE) piece_forward(w, hA, L, bo);
+        else piece_forward1(w, hA, 0xFFFF0000u, bo);
         mask_tail(bo, plen, T.nullrow);
         if (nact == 1) {
           const uint32_t leaf_end = leaf0 >> 2;
           uint32_t lmid = 0, shi = 0;
-          len0 += walk_len_mid<WIDE>(bo, leaf0, lmid, shi, L, T);
+          if constexpr (WIDE) len0 += walk_len_mid<WIDE>(bo, leaf0, lmid, shi, L, T);
+          else { uint32_t sm = 0; piece_walk1(bo, leaf0, sm, lmid, shi); len0 += sm; }
           const PieceRec rec{(int32_t)(len0 - pre0), rec_word(leaf_end, lmid, shi)};
           if (batch) {
             reinterpret_cast<PieceRec*>(lrec)[p & 7] = rec;

@@ -797,10 +797,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
     if constexpr (WIDE) piece_forward(w, hh & 0xFFFFu, L, bo);
     else piece_forward2(w, hh & 0xFFFFu, hh >> 16, 0xFFFF0000u, bo);
     mask_tail(bo, plen, T.nullrow);
+    // Touch the next iteration's input, checkpoints and records now, so that their HBM latency passes during the
+    // sweep.  The three destination registers stay reserved (they are operands of the wait below), the loads are
+    // older than every later vector-memory operation of the wave, so the compiler's own waits stay valid.
+    uint32_t pf0, pf1, pf2;
+    {
+      const uint64_t npiece = piece + (uint64_t)gridDim.x * WAVES * 64;
+      const uint64_t tp = npiece < npieces_total ? npiece : piece;
+      asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+                   : "=&v"(pf0), "=&v"(pf1), "=&v"(pf2)
+                   : "v"(in + (valid ? tp * PIECE : 0)), "v"(reinterpret_cast<const uint32_t*>(chk) + (valid ? tp : 0)), "v"(prec + (valid ? tp : 0)));
+    }
     const uint32_t leaf_end4 = (rec.leaf & 0xFFu) * 4, leaf_mid4 = ((rec.leaf >> 8) & 0xFFu) * 4, len_hi = rec.leaf >> 16;
     const unsigned long long vmask = __ballot(valid);
     const uint32_t nvalid = (uint32_t)__popcll(vmask);
     uint32_t first = 0;
+    bool pf_pending = true;
     while (first < nvalid) {
       const uint64_t gs = __shfl(ostart, first);
       const uint64_t abase = gs & ~15ull;
@@ -877,6 +889,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
         if (l & 1) dst[i] = sp[i];
       }
       wave_lds_fence();
+      if (pf_pending) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf0), "+v"(pf1), "+v"(pf2)); pf_pending = false; }
       // flush [gs, ge): partial head and tail windows bytewise, everything between as aligned 16 B
       const uint64_t ge = __shfl(oend, lastl);
       const uint64_t fs = (gs + 15) & ~15ull, fe = ge & ~15ull;
@@ -891,6 +904,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
       wave_lds_fence();
       first = lastl + 1;
     }
+    if (pf_pending) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf0), "+v"(pf1), "+v"(pf2));   // (a wave-iteration without valid pieces)
   }
 }
 

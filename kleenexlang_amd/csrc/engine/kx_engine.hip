@@ -758,7 +758,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
                                                      const unsigned long long* __restrict__ off, Flags* __restrict__ flags,
-                                                     uint32_t stgb, uint32_t jbytes, uint32_t maxcnt, uint32_t init_shift,
+                                                     uint32_t stgb, uint32_t jbytes, uint32_t maxcnt, uint32_t nup, uint32_t init_shift,
                                                      uint32_t init_leaf, int is_first, uint8_t* __restrict__ out, DevTables T) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   Lds L = stage_tables<WIDE>(T, smem);
@@ -876,17 +876,51 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
         njobs = 0;
       }
       wave_lds_fence();
-      // constants: one lane per job
-      for (uint32_t j = lane; j < njobs; j += 64) {
+      // constants: one lane per job; the first 16 bytes of a constant are fetched in one go (four independent
+      // unaligned reads; what lies beyond a constant is read and dropped), so a job is three dependent LDS round trips, not seven
+      auto job_of = [&](uint32_t j, uint32_t& l, uint8_t*& dst, const uint8_t*& sp) {
         const uint32_t jw = *reinterpret_cast<const uint32_t*>((const uint8_t*)smem + jarea + 4 * j);
-        const uint32_t a = jw & 0xFFFFu, e = L.w(a), cp = E_COPY(e);
-        const uint32_t d = stga + (((jw >> 16) - stga) & 0xFFFFu) + cp, l = ent_dlen<WIDE>(e, a, L, T) - cp, src = ent_off<WIDE>(e, a, L, T);
-        uint8_t* dst = (uint8_t*)smem + d;
-        const uint8_t* sp = L.base + L.pool + src;
-        uint32_t i = 0;   // LDS takes unaligned 4- and 2-byte accesses
-        for (; i + 4 <= l; i += 4) { uint32_t v; __builtin_memcpy(&v, sp + i, 4); __builtin_memcpy(dst + i, &v, 4); }
-        if (l & 2) { uint16_t v; __builtin_memcpy(&v, sp + i, 2); __builtin_memcpy(dst + i, &v, 2); i += 2; }
-        if (l & 1) dst[i] = sp[i];
+        const uint32_t a = jw & 0xFFFFu, e = L.w(a);
+        const uint32_t cp = E_COPY(e), src = ent_off<WIDE>(e, a, L, T);
+        l = ent_dlen<WIDE>(e, a, L, T) - cp;
+        dst = (uint8_t*)smem + stga + (((jw >> 16) - stga) & 0xFFFFu) + cp;
+        sp = L.base + L.pool + src;
+      };
+      if (nup > 1) {   // (uniform) programs with constants longer than 4 bytes
+        for (uint32_t j = lane; j < njobs; j += 64) {
+          uint32_t l; uint8_t* dst; const uint8_t* sp;
+          job_of(j, l, dst, sp);
+          uint32_t v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) __builtin_memcpy(&v[q], sp + 4 * q, 4);
+          const uint32_t nw = l >> 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if ((uint32_t)q < nw) __builtin_memcpy(dst + 4 * q, &v[q], 4);
+          if (nw < 4) {
+            uint32_t vt = nw == 0 ? v[0] : nw == 1 ? v[1] : nw == 2 ? v[2] : v[3];
+            uint8_t* dt = dst + 4 * nw;
+            if (l & 2) { const uint16_t h2 = (uint16_t)vt; __builtin_memcpy(dt, &h2, 2); dt += 2; vt >>= 16; }
+            if (l & 1) *dt = (uint8_t)vt;
+          } else {
+            uint32_t i = 16;
+            for (; i + 4 <= l; i += 4) { uint32_t x; __builtin_memcpy(&x, sp + i, 4); __builtin_memcpy(dst + i, &x, 4); }
+            if (l & 2) { uint16_t x; __builtin_memcpy(&x, sp + i, 2); __builtin_memcpy(dst + i, &x, 2); i += 2; }
+            if (l & 1) dst[i] = sp[i];
+          }
+        }
+      } else {         // every constant fits one dword
+        for (uint32_t j = lane; j < njobs; j += 64) {
+          uint32_t l; uint8_t* dst; const uint8_t* sp;
+          job_of(j, l, dst, sp);
+          uint32_t vt;
+          __builtin_memcpy(&vt, sp, 4);
+          if (l == 4) __builtin_memcpy(dst, &vt, 4);
+          else {
+            uint8_t* dt = dst;
+            if (l & 2) { const uint16_t h2 = (uint16_t)vt; __builtin_memcpy(dt, &h2, 2); dt += 2; vt >>= 16; }
+            if (l & 1) *dt = (uint8_t)vt;
+          }
+        }
       }
       wave_lds_fence();
       if (pf_pending) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf0), "+v"(pf1), "+v"(pf2)); pf_pending = false; }
@@ -918,6 +952,7 @@ struct Stage {
   DevTables T{};
   size_t lds_bytes = 0;                                // packed table image
   size_t sync_lds_bytes = 0;                           // 0 = sync tables stay in global memory
+  uint32_t emit_nup = 1;                               // k_emit: dwords of a constant fetched up front (longest constant / 4, at most 4)
   bool general = false;                                   // wide back entries or > 64 byte classes: run the GENERAL kernel instances
 };
 
@@ -1009,6 +1044,7 @@ int parseStage(const uint8_t*& c, const uint8_t* end, Stage& S) {
   auto pushEnt = [&](uint32_t parent, uint32_t copy, uint32_t dlen, uint32_t poff) {
     const bool wide = dlen >= 127 || poff >= (1u << 13);
     if (wide) S.general = true;
+    { const uint32_t need = (dlen - copy + 3) / 4; if (need > S.emit_nup) S.emit_nup = need < 4 ? need : 4; }
     ent.push_back((copy ? 0u : 1u) | (parent << 2) | ((wide ? 0u : poff) << 10) | (dlen > copy ? 1u << 23 : 0u) |
                   ((wide ? 127u : dlen) << 24));
     wlen.push_back(dlen); woff.push_back(poff);
@@ -1457,7 +1493,7 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
   hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
-                     s->prec, s->ctot, s->off, s->flags, (uint32_t)stgb, (uint32_t)jbytes, maxcnt, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
+                     s->prec, s->ctot, s->off, s->flags, (uint32_t)stgb, (uint32_t)jbytes, maxcnt, S.emit_nup, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
   if (S.general) { if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
   else { if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }
 #undef KX_LAUNCH_EMIT

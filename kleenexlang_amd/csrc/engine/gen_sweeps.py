@@ -76,7 +76,9 @@ def sweep2():
         ap("ds_read_b32 %%[e%s0], %%[a%s0]" % (ch, ch))
     for j in range(31, -1, -1):
         cur, nxt = (31 - j) & 1, (32 - j) & 1
-        ap("s_waitcnt lgkmcnt(0)")
+        # the two entry reads are the oldest operations in flight; behind them sit the previous step's two byte
+        # stores (always) and job stores (sometimes): waiting for "all but two" never waits for less than the reads
+        ap("s_waitcnt lgkmcnt(%d)" % (0 if j == 31 else 2))
         for ch in "AB":
             ap("v_and_b32 %%[leaf%s], 0x3fc, %%[e%s%d]" % (ch, ch, cur))
             if j > 0:

@@ -753,7 +753,7 @@ __device__ __forceinline__ void emit_step_gen(const uint32_t (&bo)[BOW], const u
 }
 
 template <int WAVES, bool WIDE>   // WIDE: the GENERAL instance (wide back entries / class shift), compiler-scheduled sweeps
-__global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk,
+__global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__ in, uint64_t n, uint64_t blk, uint32_t blk_shift,
                                                      uint64_t npieces_total, const uint16_t* __restrict__ chk,
                                                      const PieceRec* __restrict__ prec,
                                                      const uint32_t* __restrict__ ctot,
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_emit(const uint8_t* __restrict__
   const uint64_t nwi = (npieces_total + 63) / 64;
   const uint64_t oend_all = (uint64_t)init_shift + flags->total_len;
   auto piece_ostart = [&](uint64_t pc, const PieceRec& r) {
-    const uint64_t m = pc * PIECE / blk;
+    const uint64_t m = blk_shift < 64u ? (pc * PIECE) >> blk_shift : pc * PIECE / blk;   // (a 64-bit division costs ≈100 instructions)
     return (uint64_t)init_shift + off[m] + (uint64_t)(int64_t)((int32_t)ctot[m] - r.cum);
   };
   for (uint64_t it = (uint64_t)blockIdx.x * WAVES + wave; it < nwi; it += (uint64_t)gridDim.x * WAVES) {
@@ -1490,9 +1490,10 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap) {
   uint64_t wantg = (nwi + W - 1) / W;
   const uint32_t grid = (uint32_t)(wantg < (uint64_t)p->ncu ? wantg : (uint64_t)p->ncu);
   const size_t elds = tab + (size_t)W * (stgb + 16 + jbytes);
+  const uint32_t blk_shift = (s->seg & (s->seg - 1)) == 0 ? (uint32_t)__builtin_ctzll(s->seg) : 0xFFu;
   if (timing) HIPCHECK(hipEventRecord(p->ev[0], s->stream));
 #define KX_LAUNCH_EMIT(WV, WD)                                                                                       \
-  hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, npieces, s->chk, \
+  hipLaunchKernelGGL((k_emit<WV, WD>), dim3(grid), dim3(WV * 64), elds, s->stream, s->in, s->n, s->seg, blk_shift, npieces, s->chk, \
                      s->prec, s->ctot, s->off, s->flags, (uint32_t)stgb, (uint32_t)jbytes, maxcnt, S.emit_nup, s->init_shift, s->init_leaf, s->is_first, (uint8_t*)d_out, S.T)
   if (S.general) { if (W == 12) KX_LAUNCH_EMIT(12, true); else if (W == 8) KX_LAUNCH_EMIT(8, true); else KX_LAUNCH_EMIT(4, true); }
   else { if (W == 12) KX_LAUNCH_EMIT(12, false); else if (W == 8) KX_LAUNCH_EMIT(8, false); else KX_LAUNCH_EMIT(4, false); }

@@ -158,7 +158,8 @@ struct Parser {
     bool first = true;
     for (;;) {
       int c = peek();
-      if (c < 0 || c == '/') err("unterminated character class");
+      // an unescaped '/' is legal inside a class (ref: bench/kleenex/src/jix_responsetime.kex:23, syntax_latex.kex:81)
+      if (c < 0) err("unterminated character class");
       if (c == ']' && !first) { ++p; break; }
       first = false;
       unsigned lo;

@@ -64,3 +64,12 @@ def test_backend_c_with_restated_runtime(tmp_path):
     blob_prog = os.path.join(build.ROOT, "oracle", "_build", "x")
     p = subprocess.run([str(out)], input=b"12a", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and p.stdout == b"12a"
+
+
+def test_slash_inside_a_character_class_does_not_end_the_regex():
+    """The reference's own bench programs write an unescaped '/' inside classes
+    (ref: bench/kleenex/src/jix_responsetime.kex:23 `/\\[[A-Za-z0-9: /+-]+]/`, syntax_latex.kex:81)."""
+    from oracle import oracle
+    from conftest import blob_of
+    blob = blob_of('main := (/[a-c: /+-]+/ "." | ~/;/)*\n')
+    assert oracle.run(blob, b"a/b;c+-;: /") == b"a/b.c+-.: /."

@@ -1,0 +1,98 @@
+"""Breadth pin, runs only where the reference checkout is mounted (this container; never on the GPU box):
+every action-free program of the reference's own benchmark suite (bench/kleenex/src/*.kex) must compile,
+and on the reference's own sample data (test/data/*) the three evaluation routes — lock-step simulation of
+the nondeterministic transducer, register form, path form — must agree byte for byte.  Nothing is copied:
+programs and data are read in place."""
+import glob
+import os
+
+import pytest
+
+from kleenexlang_amd import CompileError, host
+from oracle import fst_sim, oracle
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "bench", "kleenex", "src")),
+                                reason="reference checkout not mounted")
+
+# program → sample input of the reference (bench/Makefile's data sets, test/data/*)
+DATA = {
+    "apache_log": "apache_log/example.log", "csv2json": "csv/csv_format1.sample.csv", "csv2json_nows": "csv/csv_format1.sample.csv",
+    "csv_project3": "csv/csv_format1.sample.csv", "iso_datetime_to_json": "datetime/datetime_sample.txt",
+    "thousand_sep": "numbers/numbers_small.txt", "irc": "irc/irc.txt", "url": "url/test_urls.txt", "ini2json": "ini/php.ini",
+    "issuu_fallback": "issuu/sample.json", "issuu_nofallback": "issuu/sample.json", "issuu_json2sql": "issuu/sample.json",
+    "issuu_id_fallback": "issuu/sample.json", "issuu_id_nofallback": "issuu/sample.json",
+    "aws_json2sql": "json/aws.json", "email": "email/emails_from_apache.txt", "dfamail": "email/emails_from_apache.txt",
+    "as": "strings/as_small.txt", "rot13": "strings/random_small.txt", "simple_id": "strings/random_small.txt",
+    "patho1": "strings/as_small.txt", "patho2": "strings/as_small.txt",
+}
+NEEDS_ACTIONS = {"dna_regex_noalias_2", "doc_comments", "drex_align-bibtex", "drex_rev-dict", "drex_swap-bibtex", "jix_responsetime",
+                 "markdown2html", "mitm", "sort_ab", "swap_lines", "worstcase"}
+HUGE = {"syntax"}   # 28 485 SST states: minutes in `optimize`, far outside the engine's table limits
+
+
+def _programs():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(REF, "bench", "kleenex", "src", "*.kex")))
+
+
+def _source(name):
+    return open(os.path.join(REF, "bench", "kleenex", "src", name + ".kex"), encoding="utf-8", errors="surrogateescape").read()
+
+
+def test_every_action_free_bench_program_compiles_and_fits_the_engine_limits():
+    fits = too_big = 0
+    for name in _programs():
+        if name in HUGE:
+            continue
+        if name in NEEDS_ACTIONS:
+            with pytest.raises(CompileError, match="action symbols"):   # the reference's own direct-mode error (Commands.hs:165-168)
+                host.compile_source(_source(name), opt=0)
+            continue
+        info = oracle.info(host.compile_source(_source(name), opt=3))
+        if 256 + (info["nstates"] + 1) * info["nclasses"] * 4 <= 0xFFF0:
+            fits += 1
+        else:
+            too_big += 1
+    assert fits >= 38 and too_big <= 1, (fits, too_big)   # make_danish (1039 states x 34 classes) is the one outside
+
+
+def test_three_routes_agree_on_the_reference_sample_data():
+    checked = 0
+    for name, rel in sorted(DATA.items()):
+        path = os.path.join(REF, "test", "data", rel)
+        if not os.path.exists(path):
+            continue
+        src = _source(name)
+        data = open(path, "rb").read()
+        cut = data[:6000]
+        cut = cut[:cut.rfind(b"\n") + 1] or cut      # whole lines (most programs are line oriented)
+        blob0, blob3 = host.compile_source(src, opt=0), host.compile_source(src, opt=3)
+        fsts = host.dump_fst(src)
+        results = []
+        for blob in (blob0, blob3):
+            for pf in (False, True):
+                try:
+                    results.append(oracle.run(blob, cut, path_form=pf))
+                except oracle.OracleMatchError as e:
+                    results.append(("fail", e.pos))
+        assert all(r == results[0] for r in results), name
+        if not isinstance(results[0], tuple):
+            sim = fst_sim.run(fsts, cut[:1500][:cut[:1500].rfind(b"\n") + 1] or cut[:1500])
+            short = cut[:1500][:cut[:1500].rfind(b"\n") + 1] or cut[:1500]
+            try:
+                assert sim == oracle.run(blob3, short), name
+            except oracle.OracleMatchError:
+                assert sim is None, name
+        # the whole sample, register form against path form
+        for blob in (blob3,):
+            try:
+                a = oracle.run(blob, data)
+            except oracle.OracleMatchError as e:
+                a = ("fail", e.pos)
+            try:
+                b = oracle.run(blob, data, path_form=True)
+            except oracle.OracleMatchError as e:
+                b = ("fail", e.pos)
+            assert a == b, name
+        checked += 1
+    assert checked >= 15, checked

@@ -174,6 +174,22 @@ def test_more_than_64_byte_classes_run_the_general_kernel_instances():
             assert got == want, (len(data), seg)
 
 
+def test_large_table_program_one_workgroup_per_cu():
+    """A keyword rewriter whose table image (≈ 50 KiB) no longer lets two 512-lane groups of k_backlen share a
+    CU's LDS (the kernel then runs 1024-lane groups), and leaves k_emit less LDS per wave."""
+    rng = random.Random(42)
+    words = sorted({"".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(5, 8))) for _ in range(26)})
+    alts = " | ".join('/%s/ "<%d>"' % (w, i) for i, w in enumerate(words))
+    blob = blob_of("main := (%s | /[a-z ]/)*\n" % alts)
+    info = oracle.info(blob)
+    assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 24 * 1024
+    text = " ".join(rng.choice(words + ["zz", "qq", "hello", "a"]) for _ in range(60000)).encode()
+    for data in [text[:100], text[:70000], text]:
+        for seg in (64, 4096):
+            got, want = both(blob, data, segment_bytes=seg)
+            assert got == want, (len(data), seg)
+
+
 def test_multi_stage_pipeline_on_device():
     src = 'start: p >> a >> b\np := (~/abc/ "a")*\na := (/./ "b")*\nb := (/ab/ "c" | ~/[^ab]/ "lol")*\n'
     blob = blob_of(src)

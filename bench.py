@@ -194,7 +194,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s.kex, %.2f GiB synthetic %s per GPU (seeded 32 MiB chunk replicated, "
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
-                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or "auto (4-16 KiB by input size)",
+                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
                        "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

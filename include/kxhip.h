@@ -62,7 +62,7 @@ typedef struct kx_stats {
 
 /* tuning knobs (0 = default) */
 typedef struct kx_config {
-  uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; 0 = by input size (4-16 KiB) */
+  uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; 0 = one round of lanes (4-64 KiB)  */
   uint32_t block_threads;  /* workgroup size (power of two); default 512        */
   uint32_t collect_timing; /* record per-kernel HIP events into kx_stats        */
   uint32_t pad;

@@ -87,29 +87,47 @@ def sweep2():
                 ap("ds_read_b32 %%[e%s%d], %%[a%s%d]" % (ch, nxt, ch, nxt))
         for ch in "AB":
             t = base[ch] + j
-            e, a, o = "%%[e%s%d]" % (ch, cur), "%%[a%s%d]" % (ch, cur), "%%[o%s]" % ch
+            e, o = "%%[e%s%d]" % (ch, cur), "%%[o%s]" % ch
             by = t & 3
             if by == 3:
                 ap("v_lshrrev_b32 %%[tw%s], 8, %%[w%d]" % (ch, t >> 2))
             src = "%%[tw%s]" % ch if by in (1, 3) else "%%[w%d]" % (t >> 2)
             wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
             ap("v_sub_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, e, SD))
-            ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % e)
+            ap("v_cmp_gt_i32_sdwa %s, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % ("%[mA]" if ch == "A" else "vcc", e))
             ap("v_lshl_or_b32 %s, %s, 31, %s" % (e, e, o))
             ap("%s %s, %s" % (wr, e, src))
-            ap("s_and_saveexec_b64 %[sv], vcc")
-            ap("s_cbranch_execz 1f")
-            # job slot = wave-wide running count + rank among the lanes that note a constant in this step
-            ap("v_mbcnt_lo_u32_b32 %s, exec_lo, 0" % e)
-            ap("v_mbcnt_hi_u32_b32 %s, exec_hi, %s" % (e, e))
-            ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (e, e))
-            ap("v_min_u32 %s, %%[jlim], %s" % (e, e))
-            ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
-            ap("ds_write_b32 %s, %s" % (e, a))
-            ap("1:")
-            ap("s_or_b64 exec, exec, %[sv]")
-            ap("s_bcnt1_i32_b64 %[st], vcc")
-            ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
+        # constants of both chains in one store: lanes of the union take a slot each (wave-wide running count +
+        # rank), chain A's job where there is one, else chain B's; the rare lane with both stores B's separately
+        eA, aA, aB = "%%[eA%d]" % cur, "%%[aA%d]" % cur, "%%[aB%d]" % cur
+        ap("s_or_b64 %[mU], %[mA], vcc")
+        ap("s_and_saveexec_b64 %[sv], %[mU]")
+        ap("s_cbranch_execz 1f")
+        ap("v_lshl_or_b32 %s, %%[oA], 16, %s" % (aA, aA))
+        ap("v_lshl_or_b32 %s, %%[oB], 16, %s" % (aB, aB))
+        ap("v_cndmask_b32_e64 %s, %s, %s, %%[mA]" % (aA, aB, aA))
+        ap("v_mbcnt_lo_u32_b32 %s, exec_lo, 0" % eA)
+        ap("v_mbcnt_hi_u32_b32 %s, exec_hi, %s" % (eA, eA))
+        ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (eA, eA))
+        ap("v_min_u32 %s, %%[jlim], %s" % (eA, eA))
+        ap("ds_write_b32 %s, %s" % (eA, aA))
+        ap("s_and_b64 %[mA], %[mA], vcc")
+        ap("s_cbranch_scc0 1f")
+        ap("s_bcnt1_i32_b64 %[st], %[mU]")
+        ap("s_mov_b64 exec, %[mA]")
+        ap("v_mbcnt_lo_u32_b32 %s, exec_lo, 0" % eA)
+        ap("v_mbcnt_hi_u32_b32 %s, exec_hi, %s" % (eA, eA))
+        ap("v_add_u32 %s, %%[st], %s" % (eA, eA))
+        ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (eA, eA))
+        ap("v_min_u32 %s, %%[jlim], %s" % (eA, eA))
+        ap("ds_write_b32 %s, %s" % (eA, aB))
+        ap("1:")
+        ap("s_mov_b64 exec, %[sv]")
+        ap("s_bcnt1_i32_b64 %[st], %[mU]")
+        ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
+        ap("s_and_b64 %[mA], %[mA], vcc")
+        ap("s_bcnt1_i32_b64 %[st], %[mA]")
+        ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
     return L
 
 
@@ -187,9 +205,9 @@ def main():
     emit_fn(out, "piece_sweep2",
             "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
             "uint32_t& jb, uint32_t jlim",
-            "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv;",
+            "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv, mA, mU;",
             sweep2(),
-            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[mA] "=&s"(mA)', '[mU] "=&s"(mU)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
                                                        '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
             ['[jlim] "s"(jlim)'],

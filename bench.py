@@ -3,7 +3,9 @@
 Apache log that is already resident in HBM, with the kernel roofline and a CPU baseline beside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--gib G] [--program P]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N …)
+  N > 1: either launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py --gpus N …`
+  (RANK/LOCAL_RANK/WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`, which re-executes
+  itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 A "step" is one full pass of the hot path (all engine kernels, every pipeline stage) over the
 rank's shard.  Weak scaling: every rank owns `--gib` GiB of the global log (cut mid-line); the only
@@ -29,7 +31,7 @@ def cpu_baseline(program, base, sample_bytes):
     """Time the reference CPU path on a bounded sample of the same workload, the reference's way:
     `BIN -t < file > /dev/null`, wall ms from the binary's own stderr line (bench/runningtime.sh:32)."""
     from oracle import oracle
-    kind, exe = "reference", oracle.ref_binary(program, 3)
+    kind, exe = "own-codegen+ref-crt", oracle.ref_binary(program, 3)
     if exe is None:  # no prebuilt reference-runtime binary: build generated C against the restated runtime
         kind = "port"
         from kleenexlang_amd import build, program_path
@@ -54,7 +56,7 @@ def cpu_baseline(program, base, sample_bytes):
                 "sample": "%d B (base chunk ×%d) of the same synthetic log through `%s -t < file > /dev/null`, best of 2; "
                           "generated C (kexc --backend=c --opt 3, reference shape) + %s"
                           % (nbytes, k, os.path.basename(exe),
-                             "the reference's own crt/crt.c" if kind == "reference" else "restated runtime oracle/crt_port/crt.c")}
+                             "the reference's own crt/crt.c (the reference's literal generated C needs GHC and does not exist here)" if kind != "port" else "restated runtime oracle/crt_port/crt.c")}
     finally:
         os.unlink(path)
 
@@ -73,6 +75,13 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the boundary hand-off")
     ap.add_argument("--single-device", action="store_true", help="(validation) put every rank on cuda:0")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     import torch
     from kleenexlang_amd import Program, compile_file, sharded, workloads
@@ -98,7 +107,11 @@ def main():
         else:
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     comm_dev = dev if a.backend == "nccl" else "cpu"
-    assert world == a.gpus, "launch with torch.distributed.run for --gpus > 1"
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not a.single_device and torch.cuda.device_count() < world and world > 1:
+        raise SystemExit("bench.py: %d ranks but %d visible GPUs (use --single-device to stack ranks on cuda:0 for validation)"
+                         % (world, torch.cuda.device_count()))
 
     blob = compile_file(a.program)
     prog = Program(blob, segment_bytes=a.segment, block_threads=a.block_threads, collect_timing=True)
@@ -123,7 +136,7 @@ def main():
     out = torch.empty(int(n_local * expansion) + (1 << 20), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    totals = {"out": None}
+    totals = {"out": None, "off": 0}
 
     def step():
         if not use_dist:
@@ -133,7 +146,7 @@ def main():
         sh.emit(out.data_ptr(), out.numel())
         prog.last_stats = sh.stats()
         sh.end()
-        totals["out"] = res[3]
+        totals["out"], totals["off"] = res[3], res[2]
         return res[1]
 
     def fence():
@@ -157,17 +170,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # correctness spot check outside the timed region (bit-exact on the first shard's first chunk)
-    ok = None
-    if rank == 0:
-        want = oracle.run(blob, base)
-        head = bytes(out[:min(olen, 1 << 20)].cpu().numpy().tobytes())
-        ok = head == want[:len(head)] if world == 1 or n_local >= len(base) else None
-        if ok and totals["out"] is not None and a.program in ("apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"):
-            # whole-job output length must equal that of the replicated base chunk (tiled_expected)
-            reps = n_global // len(base)
-            exp_total = (len(want) - 4 + 2) * (reps - 1) + len(want) if a.program == "apache_log" else len(want) * reps
-            ok = ok and totals["out"] == exp_total
+    # Bit-exact check of EVERY output byte, outside the timed region and on the device: the expected stream of
+    # the replicated input is (prefix, unit × reps, suffix) built from the CPU oracle's output on ONE base chunk
+    # (workloads.tiled_parts); each rank compares its slice [out_offset, out_offset + out_len) of that stream.
+    want = oracle.run(blob, base)
+    parts = workloads.tiled_parts(a.program, want, n_global // len(base))
+    my_off = totals["off"] if use_dist else 0
+    ok = workloads.check_tiled_on_device(out[:olen], my_off, parts)
+    checked = olen
+    total_out = totals["out"] if use_dist else olen
+    if dist is not None:
+        agg = torch.tensor([1 if ok else 0, checked], dtype=torch.int64, device=comm_dev)
+        okt = agg[:1].clone(); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        cnt = agg[1:].clone(); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        ok, checked = bool(int(okt.item())), int(cnt.item())
+    ok = bool(ok) and total_out == workloads.tiled_total(parts) and checked == total_out
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -175,18 +192,24 @@ def main():
         kern = {k: v / a.steps for k, v in kern.items()}
         dom = max(kern, key=kern.get)
         ratio = olen / float(n_local)
-        # algorithmic HBM bytes of one launch of each kernel, per input byte
-        alg = {"sync": 0.0, "forward": 1.0, "head": 0.0, "backlen": 1.0, "resolve": 0.0, "emit": 1.0 + ratio}
-        achieved = alg[dom] * n_local / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
         ksum = sum(kern.values())
-        traffic = None   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-        try:
+        # algorithmic bytes = 1 B read per input byte; `achieved` = input bytes of one launch ÷ the dominant
+        # kernel's mean launch duration (HIP events on the engine's stream, recorded by the engine around each kernel).
+        achieved = n_local / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
+        # the same kernel's own traffic (what it must read and write per input byte) — NOT the roofline fraction
+        alg = {"sync": 0.0, "forward": 1.0, "head": 0.0, "backlen": 1.0, "resolve": 0.0, "emit": 1.0 + ratio}
+        traffic, traffic_note = None, "no PMC passes for this build"
+        try:   # HBM bytes per launch of the dominant kernel from the PMC passes — only if they were taken with THIS engine build
             import glob
-            tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))[-1]))   # latest PMC passes
-            if a.program == "apache_log" and abs(tj["input_bytes"] - n_local) < (1 << 20):
-                traffic = tj["per_launch"]["k_" + dom]["total"]
-        except Exception:
-            traffic = None
+            from kleenexlang_amd import build as kbuild
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")), reverse=True):
+                tj = json.load(open(f))
+                if tj.get("engine_sha") == kbuild.engine_sha() and tj.get("program", "apache_log") == a.program and abs(tj["input_bytes"] - n_local) < (1 << 20):
+                    traffic = tj["per_launch"]["k_" + dom]["total"]
+                    traffic_note = os.path.basename(f)
+                    break
+        except Exception as e:   # noqa: BLE001
+            traffic_note = "unreadable: %s" % e
         line = {
             "metric": "input GB/s + % HBM-read roofline, apache_log.kex over 10 GiB synthetic log",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -194,15 +217,20 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s.kex, %.2f GiB synthetic %s per GPU (seeded 32 MiB chunk replicated, "
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
-                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
-                       "parallelism": "shard%d" % world},
+                       "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "output_bytes_total": total_out,
+                       "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
+                       "parallelism": "shard%d" % world, "boundary_backend": (a.backend if use_dist else None),
+                       "single_device_validation": bool(a.single_device)},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_input_byte": alg[dom]},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_note,
+                         "algorithmic_bytes_per_input_byte": 1.0},
+            "whole_path": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,
+                           "frac_of_hbm_peak": round(n_local / (ksum / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if ksum else None},
+            "dominant_kernel_own_traffic": {"bytes_per_input_byte": round(alg[dom], 4),
+                                            "GBps": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9, 2) if kern[dom] > 0 else None,
+                                            "frac_of_hbm_peak": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if kern[dom] > 0 else None},
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
-            "input_read_roofline": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,
-                                    "frac_of_hbm_peak": round(n_local / (ksum / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if ksum else None},
-            "output_checked_bit_exact": ok,
+            "output_checked_bit_exact": ok, "output_bytes_checked": checked,
         }
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.program, base, 1 << 30)

@@ -74,6 +74,21 @@ def build_engine(force=False):
     return lib, drv
 
 
+def engine_sha():
+    """sha256 (16 hex digits) over the engine's sources: stamps profiles/*traffic.json so that bench.py only quotes
+    PMC traffic that was measured with the engine build it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(CSRC, "engine")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".py", ".cpp", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(ROOT, "include", "kxp_format.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_all(force=False):
     build_kexc(force)
     build_engine(force)

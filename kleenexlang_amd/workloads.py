@@ -118,3 +118,74 @@ def device_input(program, nbytes, device, base_bytes=32 << 20, seed=0x4B4C4558):
     tb = torch.frombuffer(bytearray(base), dtype=torch.uint8).to(device)
     t = tb.repeat(k) if k > 1 else tb
     return t, base, k
+
+
+def tiled_parts(program, base_out, k):
+    """The expected output of `program` on (base chunk × k) as (prefix, unit, reps, suffix):
+    prefix ++ unit × reps ++ suffix.  The same statement as `tiled_expected`, in a form that can be
+    checked piecewise at any size (and at any offset: see `check_tiled_on_device`)."""
+    if program == "apache_log":   # "[" (R ",\n")^(k-1) R "\n]\n"
+        assert base_out[:1] == b"[" and base_out[-3:] == b"\n]\n"
+        body = base_out[1:-3]
+        return b"[", body + b",\n", k - 1, body + b"\n]\n"
+    if program in ("csv2json", "iso_datetime_to_json", "thousand_sep"):
+        return b"", base_out, k, b""
+    raise KeyError(program)
+
+
+def tiled_total(parts):
+    prefix, unit, reps, suffix = parts
+    return len(prefix) + len(unit) * reps + len(suffix)
+
+
+def check_tiled_on_device(out, offset, parts, chunk_bytes=256 << 20):
+    """True iff the CUDA uint8 tensor `out` equals bytes [offset, offset + out.numel()) of the stream
+    described by `parts` (see `tiled_parts`).  Every byte is compared, on the device, in bounded
+    chunks — this is how 10 GiB runs are verified bit-exactly without a CPU pass (the unit's content
+    comes from the CPU oracle run on ONE base chunk)."""
+    import torch
+    prefix, unit, reps, suffix = parts
+    dev = out.device
+    n = out.numel()
+    total = tiled_total(parts)
+    if offset < 0 or offset + n > total:
+        return False
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev) if len(b) else torch.empty(0, dtype=torch.uint8, device=dev)
+    pos, end = offset, offset + n          # positions in the expected stream
+    def take(lo, hi):                       # the slice of `out` holding stream positions [lo, hi)
+        return out[lo - offset:hi - offset]
+    # prefix
+    if pos < len(prefix):
+        hi = min(end, len(prefix))
+        if not torch.equal(take(pos, hi), to_dev(prefix[pos:hi])):
+            return False
+        pos = hi
+    # repeated unit
+    u0, u1 = len(prefix), len(prefix) + len(unit) * reps
+    if pos < min(end, u1) and len(unit):
+        U = len(unit)
+        ud = to_dev(unit)
+        hi = min(end, u1)
+        # ragged head up to the next unit boundary
+        ph = (pos - u0) % U
+        if ph:
+            h = min(hi, pos + (U - ph))
+            if not torch.equal(take(pos, h), ud[ph:ph + (h - pos)]):
+                return False
+            pos = h
+        per = max(1, chunk_bytes // U)
+        while pos + U <= hi:
+            c = min(per, (hi - pos) // U)
+            if not bool((take(pos, pos + c * U).view(c, U) == ud).all()):
+                return False
+            pos += c * U
+        if pos < hi:                        # ragged tail
+            if not torch.equal(take(pos, hi), ud[:hi - pos]):
+                return False
+            pos = hi
+    # suffix
+    if pos < end:
+        s0 = u1
+        if not torch.equal(take(pos, end), to_dev(suffix[pos - s0:end - s0])):
+            return False
+    return True

@@ -144,7 +144,10 @@ class CpuShard:
         b = _Bwd()
         nle = int(self.t.nleaves[self.end])
         self.walks = {e: self._walk(e) for e in range(nle)}
-        starts = [self.walks[e][0] for e in range(nle)]
+        if self.last:   # a last shard ends in the final state's leaf whatever the neighbour assumes
+            starts = [self.walks[int(self.t.fin_leaf[self.end])][0]] * nle
+        else:
+            starts = [self.walks[e][0] for e in range(nle)]
         b.nleaves = nle
         b.constant = 1 if len(set(starts)) == 1 else 0
         b.start_leaf = bytes(starts + [0] * (256 - nle))

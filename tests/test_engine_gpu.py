@@ -282,3 +282,25 @@ def test_produced_binary_streams_inputs_in_windows(tmp_path):
             r = subprocess.run([str(exe)], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KX_WINDOW_BYTES="65536"))
             assert r.returncode == 1 and r.stderr.endswith(b"Match error at input symbol %d!\n" % pos), (name, r.stderr[-100:])
             assert want.startswith(r.stdout[:len(r.stdout)]) or name == "two_stage"
+
+
+def test_windowed_multi_stage_last_window_emits_nothing(tmp_path):
+    """when the last window of stage 1 produces no bytes, stage 2 receives an empty LAST window behind
+    pending ones; the pending window must then be resolved with the final state's leaf."""
+    import subprocess
+    from kleenexlang_amd import build
+    kexc = os.path.join(build.OUT, "kexc")
+    src = ('start: strip >> lines\n'
+           'strip := (~/x/ | /[a\\n]/)*\n'
+           'lines := /a+\\n/ rest\nrest := "," lines | "."\n')
+    path = tmp_path / "two.kex"
+    path.write_text(src)
+    exe = tmp_path / "two"
+    assert subprocess.run([kexc, "compile", "--quiet", str(path), "--out", str(exe)]).returncode == 0
+    data = (b"aaa\n" * 3000) + b"x" * 20000          # the trailing windows hold only suppressed bytes
+    want = oracle.run(blob_of(src), data)
+    assert want.endswith(b"aaa\n.") and want.count(b",") == 2999
+    for window in (4096, 8192, 1 << 20):
+        r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, KX_WINDOW_BYTES=str(window)))
+        assert r.returncode == 0 and r.stdout == want, (window, r.stderr[-200:], r.stdout[-20:])

@@ -118,3 +118,44 @@ def test_hip_shards_in_one_process(prog, shape):
             s.end()
         assert b"".join(outs) == want, (prog, world)
         for p in progs: p.close()
+
+
+def test_empty_last_shard_resolves_its_predecessor_with_the_final_leaf():
+    """a last shard (or window) with n == 0 must hand back the FINAL state's leaf, not the identity map —
+    otherwise the shard before it is resolved with end leaf 0 and silently emits another path's output."""
+    sys.path.insert(0, HERE)
+    import kxp
+    for prog, shape in [("apache_log", "apache_log"), ("csv2json", "csv"), ("iso_datetime_to_json", "datetime")]:
+        data = workloads.generate(shape, 4000, 35)
+        stage = kxp.parse(blob_of(prog))[0]
+        for parts in ([data, b""], [data[:1500], data[1500:], b""], [b"", data, b""]):
+            shards = [kxp.CpuShard(stage, p, i == 0, i == len(parts) - 1) for i, p in enumerate(parts)]
+            res = sharded.run_stage_local(shards, [len(p) for p in parts])
+            assert all(r[0] == "ok" for r in res)
+            assert b"".join(s.emit() for s in shards) == oracle.run(blob_of(prog), data), (prog, [len(p) for p in parts])
+
+
+@pytest.mark.gpu
+def test_hip_empty_last_and_empty_middle_shards():
+    import torch
+    from kleenexlang_amd import Program
+    for prog, shape in [("apache_log", "apache_log"), ("csv2json", "csv"), ("iso_datetime_to_json", "datetime")]:
+        blob = blob_of(prog)
+        data = workloads.generate(shape, 300000, 36)
+        want = oracle.run(blob, data)
+        cut = (len(data) // 2) // 16 * 16
+        for parts in ([data, b""], [data[:cut], b"", data[cut:]], [data[:cut], data[cut:], b""]):
+            world = len(parts)
+            tens = [torch.frombuffer(bytearray(p if p else b"\0" * 16), dtype=torch.uint8).to("cuda:0") for p in parts]
+            progs = [Program(blob, segment_bytes=1024) for _ in range(world)]
+            shards = [progs[i].shard_begin(0, tens[i].data_ptr(), len(parts[i]), i == 0, i == world - 1) for i in range(world)]
+            res = sharded.run_stage_local(shards, [len(p) for p in parts])
+            assert all(r[0] == "ok" for r in res), res
+            outs = []
+            for i, s in enumerate(shards):
+                o = torch.empty(max(res[i][1], 16), dtype=torch.uint8, device="cuda:0")
+                s.emit(o.data_ptr(), res[i][1])
+                outs.append(bytes(o[:res[i][1]].cpu().numpy().tobytes()))
+                s.end()
+            assert b"".join(outs) == want, (prog, [len(p) for p in parts])
+            for p in progs: p.close()

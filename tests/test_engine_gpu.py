@@ -304,3 +304,41 @@ def test_windowed_multi_stage_last_window_emits_nothing(tmp_path):
         r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            env=dict(os.environ, KX_WINDOW_BYTES=str(window)))
         assert r.returncode == 0 and r.stdout == want, (window, r.stderr[-200:], r.stdout[-20:])
+
+
+@pytest.mark.parametrize("prog", ["apache_log", "csv2json", "iso_datetime_to_json"])
+def test_baseline_10gib_configs_every_output_byte_checked_on_device(prog):
+    """BASELINE configs 3 and 5 (and the headline apache_log run) at their full 10 GiB, with the segment size the
+    engine picks itself at that size: EVERY output byte is compared on the device with the tiled expectation built
+    from the CPU oracle's output on one base chunk (the reference's equality check is on full outputs, bench/Makefile:73-127)."""
+    import torch
+    blob = blob_of(prog)
+    t, base, k = workloads.device_input(prog, 10 << 30, "cuda:0", base_bytes=8 << 20)
+    parts = workloads.tiled_parts(prog, oracle.run(blob, base), k)
+    total = workloads.tiled_total(parts)
+    out = torch.empty(total + 4096, dtype=torch.uint8, device="cuda:0")
+    p = Program(blob)
+    ol = p.run_device(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ol == total
+    assert workloads.check_tiled_on_device(out[:ol], 0, parts)
+    p.close()
+    del out, t
+    torch.cuda.empty_cache()
+
+
+def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
+    """The sharded protocol over the real `nccl` (= RCCL) backend: bench.py launches itself with N ranks stacked on
+    cuda:0 (the box has one GPU), every rank runs real HIP shards, the boundary tuples travel through RCCL
+    all-gathers, and every output byte of every rank is verified on the device."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for world in (2, 4):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--single-device", "--gib", "0.25",
+                            "--steps", "2", "--warmup", "1", "--no-cpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        line = json.loads([x for x in r.stdout.decode().splitlines() if x.startswith('{"metric"')][-1])
+        assert line["n_gpus"] == world and line["config"]["boundary_backend"] == "nccl"
+        assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]

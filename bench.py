@@ -99,6 +99,13 @@ def main():
     dist = None
     use_dist = world > 1 or a.force_dist
     if use_dist:
+        if a.single_device and world > 1 and a.backend == "nccl":
+            # RCCL refuses two ranks on one device ("Duplicate GPU detected") by comparing (host hash, PCI bus id).  A 1-GPU
+            # box can still run the N-rank hand-off through RCCL when every rank claims its own host id: RCCL then treats
+            # the ranks as N single-GPU nodes and carries the (≤ 300-byte) all-gathers over its socket transport on lo.
+            os.environ["NCCL_HOSTID"] = "kx-single-device-rank-%d" % rank
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -186,6 +186,63 @@ def walk1():
     return L
 
 
+def place1():
+    """The output stage's dense sweep (k_emit2): no table is consulted.  info holds one byte per step of the piece —
+    bits 0-6 the bytes that step appends (1 for a plain copy), bit 7 "the input byte is not copied" — prepared from
+    the piece's break records.  The cursor runs down the staging area; per step: cursor -= appended; the input byte
+    is stored at the cursor (bit 7, sign-extended and or-ed in, sends the store of a step that copies nothing out of
+    range: the hardware drops it).  3.75 instructions per byte, no LDS read, no wait."""
+    L = []
+    ap = L.append
+    for t in range(63, -1, -1):
+        wi, k = t >> 2, t & 3
+        if k == 3:
+            ap("v_and_b32 %%[d], %%[c7f], %%[i%d]" % wi)
+            ap("v_and_b32 %%[n], %%[c80], %%[i%d]" % wi)
+            ap("v_lshrrev_b32 %%[tw], 8, %%[w%d]" % wi)
+        ap("v_sub_u32_sdwa %%[o], %%[o], %%[d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (SD, k))
+        ap("v_or_b32_sdwa %%[a], %%[o], sext(%%[n]) %s src0_sel:DWORD src1_sel:BYTE_%d" % (SD, k))
+        src = "%[tw]" if k in (1, 3) else "%%[w%d]" % wi
+        ap("%s %%[a], %s" % ("ds_write_b8_d16_hi" if k >= 2 else "ds_write_b8", src))
+    return L
+
+
+def scatter16():
+    """k_emit2: the lane's first sixteen break records (descending step order) become info bytes and constant jobs.
+    record r = appended bytes (bits 0-6) | not copied (bit 7) | step t (bits 8-13) | action id (bits 16-31).
+      info byte:  lds8[ial + t] = r.byte0
+      job:        where the record appends a constant (action id != 0), slot jn of the lane's own slots gets
+                  action id << 16 | low 16 bits of E, E = LDS address one past the end of this step's output
+                    = c1 + k + t - (bytes appended by the lane's records 0..k-1),  c1 = piece's staging end - plen + 1
+    Lanes without a record k are masked; the wave leaves as soon as no lane has one (nmax = most records of any lane)."""
+    L = []
+    ap = L.append
+    ap("s_mov_b64 %[sv], exec")
+    for k in range(16):
+        r = "%%[r%d]" % k
+        ap("s_cmp_le_u32 %%[nmax], %d" % k)
+        ap("s_cbranch_scc1 9f")
+        ap("v_cmp_lt_u32 vcc, %d, %%[nrec]" % k)
+        ap("s_and_b64 exec, %[sv], vcc")
+        ap("v_add_u32_sdwa %%[a], %%[ial], %s %s src0_sel:DWORD src1_sel:BYTE_1" % (r, SD))
+        ap("ds_write_b8 %%[a], %s" % r)
+        ap("v_sub_u32 %[x], %[c1], %[S]")
+        ap("v_and_b32 %%[dl], 0x7f, %s" % r)
+        ap("v_add_u32 %[S], %[S], %[dl]")
+        ap("v_add_u32_sdwa %%[x], %%[x], %s %s src0_sel:DWORD src1_sel:BYTE_1" % (r, SD))
+        if k:
+            ap("v_add_u32 %%[x], %d, %%[x]" % k)
+        ap("v_cmp_lt_u32 vcc, %%[cff], %s" % r)
+        ap("v_bfi_b32 %%[x], %%[cff], %%[x], %s" % r)
+        ap("v_lshl_add_u32 %[a], %[jn], 2, %[ja]")
+        ap("v_cndmask_b32 %[a], %[oob], %[a], vcc")
+        ap("ds_write_b32 %[a], %[x]")
+        ap("v_addc_co_u32 %[jn], vcc, 0, %[jn], vcc")
+    ap("9:")
+    ap("s_mov_b64 exec, %[sv]")
+    return L
+
+
 def emit_fn(out, name, sig, decl, lines, outs, ins, clob):
     out.write("__device__ __forceinline__ void %s(%s) {\n" % (name, sig))
     if decl:
@@ -245,6 +302,28 @@ def main2(out):
             '"memory"')
 
 
+def main3(out):
+    tmp = ["d", "n", "a", "tw"]
+    emit_fn(out, "piece_place1",
+            "const uint32_t (&w)[16], const uint32_t (&info)[16], uint32_t o",
+            "uint32_t " + ", ".join(tmp) + ";",
+            place1(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[o] "+v"(o)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[i%d] "v"(info[%d])' % (i, i) for i in range(16)] +
+            ['[c7f] "s"(0x7f7f7f7fu)', '[c80] "s"(0x80808080u)'],
+            '"memory"')
+    tmp = ["a", "x", "dl"]
+    emit_fn(out, "piece_scatter16",
+            "const uint32_t (&r)[16], uint32_t nrec, uint32_t nmax, uint32_t ial, uint32_t c1, uint32_t ja, uint32_t& S, uint32_t& jn",
+            "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
+            scatter16(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[S] "+v"(S)', '[jn] "+v"(jn)', '[sv] "=&s"(sv)'],
+            ['[r%d] "v"(r[%d])' % (i, i) for i in range(16)] + ['[nrec] "v"(nrec)', '[nmax] "s"(nmax)', '[ial] "v"(ial)', '[c1] "v"(c1)',
+                                                               '[ja] "v"(ja)', '[cff] "s"(0xffffu)', '[oob] "v"(0x80000000u)'],
+            '"vcc", "scc", "memory"')
+
+
 if __name__ == "__main__":
     main()
     main2(sys.stdout)
+    main3(sys.stdout)

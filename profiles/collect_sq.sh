@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for c in GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS; do
+for c in ${SQC:-GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL}; do
   rm -rf /tmp/pmc_$c
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --gib 2 > /tmp/pmc_$c.log 2>&1
   cp $(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1) /tmp/pmc_$c.csv
@@ -25,7 +25,7 @@ for f in glob.glob("/tmp/pmc_*.csv"):
     for k, (n, v) in acc.items():
         res[k][c] = v / n
 json.dump({"workload": "apache_log 2 GiB, per launch (device totals)", "kernels": res}, open(out + "/sq_counters.json", "w"), indent=1)
-for k in ("k_emit", "k_backlen", "k_forward"):
+for k in [x for x in ("k_emit2", "k_emit", "k_backlen", "k_forward") if x in res]:
     d = res[k]
     print(k, "LDS active / CU-cycles = %.2f" % (d["SQ_LDS_IDX_ACTIVE"] / 256 / (d["GRBM_GUI_ACTIVE"] / 8)),
           "conflict share = %.2f" % (d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]),

@@ -211,8 +211,8 @@ def scatter16():
     """k_emit2: the lane's first sixteen break records (descending step order) become info bytes and constant jobs.
     record r = appended bytes (bits 0-6) | not copied (bit 7) | step t (bits 8-13) | action id (bits 16-31).
       info byte:  lds8[ial + t] = r.byte0
-      job:        where the record appends a constant (action id != 0), slot jn of the lane's own slots gets
-                  action id << 16 | low 16 bits of E, E = LDS address one past the end of this step's output
+      job:        slot k of the lane's own slots gets action id << 16 | low 16 bits of E (action id 0: nothing to copy),
+                  E = LDS address one past the end of this step's output
                     = c1 + k + t - (bytes appended by the lane's records 0..k-1),  c1 = piece's staging end - plen + 1
     Lanes without a record k are masked; the wave leaves as soon as no lane has one (nmax = most records of any lane)."""
     L = []
@@ -232,14 +232,129 @@ def scatter16():
         ap("v_add_u32_sdwa %%[x], %%[x], %s %s src0_sel:DWORD src1_sel:BYTE_1" % (r, SD))
         if k:
             ap("v_add_u32 %%[x], %d, %%[x]" % k)
-        ap("v_cmp_lt_u32 vcc, %%[cff], %s" % r)
         ap("v_bfi_b32 %%[x], %%[cff], %%[x], %s" % r)
-        ap("v_lshl_add_u32 %[a], %[jn], 2, %[ja]")
-        ap("v_cndmask_b32 %[a], %[oob], %[a], vcc")
-        ap("ds_write_b32 %[a], %[x]")
-        ap("v_addc_co_u32 %[jn], vcc, 0, %[jn], vcc")
+        ap("ds_write_b32 %%[ja], %%[x] offset:%d" % (4 * k))
     ap("9:")
     ap("s_mov_b64 exec, %[sv]")
+    return L
+
+
+def backloop():
+    """k_backlen2's flat loop (programs without wide entries): every lane walks its own block backward at its own pace,
+    one table access per trip.  A trip handles step p and, when the entry read is flagged E_FIXED, every step below it
+    down to the first step of its run (never past the start of the piece, so that every piece gets its record):
+      a = run.row + leaf;  e = lds[a];  leaf = e & 0x3fc
+      lo = fixed(e) ? max(run.pos, floor) : p;  cum += e.appended + (p - lo);  p = lo - 1
+      break record (steps that append a constant or do not copy) into the lane's ring of 16
+      p < run.pos: next run — the entry fetched one run ahead becomes current, the one below it is requested
+      p < floor:   piece complete — {cum, record offset} into the lane's ring of 8 piece records
+    Every 4th / 8th trip is a wave-wide checkpoint where whole 32-byte sectors leave the rings.  Runs are read as
+    packed entries (row << 16 | position) and used through SDWA operands without unpacking."""
+    L = []
+    ap = L.append
+    ap("s_mov_b64 %[sfull], exec")
+    ap("0:")
+    ap("v_cmp_ge_i32 vcc, %[p], %[plim]")
+    ap("s_and_b64 exec, %[sfull], vcc")
+    ap("s_cbranch_execz 9f")
+    ap("v_add_u32_sdwa %%[a], %%[leaf], %%[qcur] %s src0_sel:DWORD src1_sel:WORD_1" % SD)
+    ap("ds_read_b32 %[e], %[a]")
+    ap("v_max_i32_sdwa %%[lo], %%[floor], %%[qcur] %s src0_sel:DWORD src1_sel:WORD_0" % SD)
+    ap("v_and_b32 %[tt], 63, %[p]")
+    ap("s_waitcnt lgkmcnt(0)")
+    ap("v_and_b32 %[t1], 2, %[e]")
+    ap("v_cmp_ne_u32 vcc, 0, %[t1]")
+    ap("v_cndmask_b32 %[lo], %[p], %[lo], vcc")
+    ap("v_and_b32 %[leaf], 0x3fc, %[e]")
+    ap("v_lshrrev_b32 %[dl], 24, %[e]")
+    ap("v_sub_u32 %[t1], %[p], %[lo]")
+    ap("v_add3_u32 %[cum], %[cum], %[dl], %[t1]")
+    ap("v_add_u32 %[p], -1, %[lo]")
+    # break record
+    ap("v_and_b32 %[t1], %[cbrk], %[e]")
+    ap("v_cmp_ne_u32 vcc, 0, %[t1]")
+    ap("v_and_b32 %[t2], 1, %[e]")
+    ap("v_lshl_or_b32 %[rec], %[t2], 7, %[dl]")
+    ap("v_lshl_or_b32 %[rec], %[tt], 8, %[rec]")
+    ap("v_bfe_u32 %[t2], %[e], 10, 13")
+    ap("v_lshl_or_b32 %[rec], %[t2], 16, %[rec]")
+    ap("v_and_b32 %[t2], 15, %[boff]")
+    ap("v_lshl_add_u32 %[t2], %[t2], 2, %[rring]")
+    ap("v_cndmask_b32 %[t2], %[oob], %[t2], vcc")
+    ap("ds_write_b32 %[t2], %[rec]")
+    ap("v_addc_co_u32 %[boff], vcc, 0, %[boff], vcc")
+    # next run
+    ap("v_cmp_lt_i32_sdwa vcc, %[p], %[qcur] src0_sel:DWORD src1_sel:WORD_0")
+    ap("s_and_saveexec_b64 %[sv], vcc")
+    ap("s_cbranch_execz 1f")
+    ap("s_waitcnt vmcnt(0)")
+    ap("v_sub_u32 %[qcur], %[qn], %[ceo]")      # (rows are image offsets; the tables are staged from off_ent on)
+    ap("global_load_dword %[qn], %[va], %[tbase]")
+    ap("v_add_u32 %[va], -4, %[va]")
+    ap("1:")
+    ap("s_mov_b64 exec, %[sv]")
+    # piece complete
+    ap("v_cmp_lt_i32 vcc, %[p], %[floor]")
+    ap("s_and_saveexec_b64 %[sv], vcc")
+    ap("s_cbranch_execz 2f")
+    ap("v_and_b32 %[t1], 7, %[pp]")
+    ap("v_lshl_add_u32 %[t1], %[t1], 3, %[pring]")
+    ap("v_sub_u32 %[t2], %[boff], %[pb0]")
+    ap("v_max_u32 %[kmax], %[kmax], %[t2]")
+    ap("v_lshl_or_b32 %[t2], %[pb0], 14, %[t2]")
+    ap("ds_write_b32 %[t1], %[cum]")
+    ap("ds_write_b32 %[t1], %[t2] offset:4")
+    ap("v_mov_b32 %[pb0], %[boff]")
+    ap("v_add_u32 %[pp], -1, %[pp]")
+    ap("v_add_u32 %[floor], -64, %[floor]")
+    ap("2:")
+    ap("s_mov_b64 exec, %[sv]")
+    # trip counter; checkpoints
+    ap("s_add_u32 %[tick], %[tick], 1")
+    ap("s_and_b32 %[st], %[tick], 3")
+    ap("s_cmp_lg_u32 %[st], 0")
+    ap("s_cbranch_scc1 0b")
+    ap("s_mov_b64 exec, %[sfull]")
+    ap("s_waitcnt lgkmcnt(0)")
+    # piece records: pieces [ptop-4, ptop) complete?  (ptop - 4 > pp)
+    ap("v_add_u32 %[t1], -4, %[ptop]")
+    ap("v_cmp_gt_i32 vcc, %[t1], %[pp]")
+    ap("s_and_saveexec_b64 %[sv], vcc")
+    ap("s_cbranch_execz 3f")
+    ap("v_and_b32 %[t2], 4, %[t1]")
+    ap("v_lshl_add_u32 %[t2], %[t2], 3, %[pring]")
+    ap("ds_read_b128 %[x0], %[t2]")
+    ap("ds_read_b128 %[x1], %[t2] offset:16")
+    ap("v_add_u32 %[pa], -32, %[pa]")
+    ap("v_mov_b32 %[ptop], %[t1]")
+    ap("s_waitcnt lgkmcnt(0)")
+    ap("global_store_dwordx4 %[pa], %[x0], %[pbase]")
+    ap("global_store_dwordx4 %[pa], %[x1], %[pbase] offset:16")
+    ap("3:")
+    ap("s_mov_b64 exec, %[sv]")
+    ap("s_and_b32 %[st], %[tick], 7")
+    ap("s_cmp_lg_u32 %[st], 0")
+    ap("s_cbranch_scc1 0b")
+    # break records: eight pending?
+    ap("v_sub_u32 %[t1], %[boff], %[bfl]")
+    ap("v_cmp_lt_u32 vcc, 7, %[t1]")
+    ap("s_and_saveexec_b64 %[sv], vcc")
+    ap("s_cbranch_execz 4f")
+    ap("v_and_b32 %[t2], 8, %[bfl]")
+    ap("v_lshl_add_u32 %[t2], %[t2], 2, %[rring]")
+    ap("ds_read_b128 %[x0], %[t2]")
+    ap("ds_read_b128 %[x1], %[t2] offset:16")
+    ap("v_add_u32 %[bfl], 8, %[bfl]")
+    ap("s_waitcnt lgkmcnt(0)")
+    ap("global_store_dwordx4 %[ba], %[x0], %[bbase]")
+    ap("global_store_dwordx4 %[ba], %[x1], %[bbase] offset:16")
+    ap("v_add_u32 %[ba], 32, %[ba]")
+    ap("4:")
+    ap("s_mov_b64 exec, %[sv]")
+    ap("s_branch 0b")
+    ap("9:")
+    ap("s_mov_b64 exec, %[sfull]")
+    ap("s_waitcnt vmcnt(0) lgkmcnt(0)")   # (the entry requested last must not land in a register the compiler has reused)
     return L
 
 
@@ -314,12 +429,26 @@ def main3(out):
             '"memory"')
     tmp = ["a", "x", "dl"]
     emit_fn(out, "piece_scatter16",
-            "const uint32_t (&r)[16], uint32_t nrec, uint32_t nmax, uint32_t ial, uint32_t c1, uint32_t ja, uint32_t& S, uint32_t& jn",
+            "const uint32_t (&r)[16], uint32_t nrec, uint32_t nmax, uint32_t ial, uint32_t c1, uint32_t ja, uint32_t& S",
             "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
             scatter16(),
-            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[S] "+v"(S)', '[jn] "+v"(jn)', '[sv] "=&s"(sv)'],
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[S] "+v"(S)', '[sv] "=&s"(sv)'],
             ['[r%d] "v"(r[%d])' % (i, i) for i in range(16)] + ['[nrec] "v"(nrec)', '[nmax] "s"(nmax)', '[ial] "v"(ial)', '[c1] "v"(c1)',
-                                                               '[ja] "v"(ja)', '[cff] "s"(0xffffu)', '[oob] "v"(0x80000000u)'],
+                                                               '[ja] "v"(ja)', '[cff] "s"(0xffffu)'],
+            '"vcc", "scc", "memory"')
+
+
+def main4(out):
+    emit_fn(out, "back_loop",
+            "BackState& S, uint32_t plim, uint32_t ceo, unsigned long long tbase, unsigned long long pbase, unsigned long long bbase",
+            "uint32_t a, e, lo, tt, t1, t2, dl, rec, st; u32x4 x0, x1; unsigned long long sfull, sv;",
+            backloop(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in ("a", "e", "lo", "tt", "t1", "t2", "dl", "rec", "x0", "x1")] +
+            ['[st] "=&s"(st)', '[sfull] "=&s"(sfull)', '[sv] "=&s"(sv)'] +
+            ['[%s] "+v"(S.%s)' % (t, t) for t in ("p", "floor", "pp", "leaf", "cum", "qcur", "qn", "va", "boff", "bfl", "pb0", "kmax", "ptop", "pa", "ba")] +
+            ['[tick] "+s"(S.tick)'],
+            ['[plim] "v"(plim)', '[rring] "v"(S.rring)', '[pring] "v"(S.pring)', '[oob] "v"(0x80000000u)', '[cbrk] "s"(0x800001u)', '[ceo] "s"(ceo)',
+             '[tbase] "s"(tbase)', '[pbase] "s"(pbase)', '[bbase] "s"(bbase)'],
             '"vcc", "scc", "memory"')
 
 
@@ -327,3 +456,4 @@ if __name__ == "__main__":
     main()
     main2(sys.stdout)
     main3(sys.stdout)
+    main4(sys.stdout)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # quick GPU check: engine parity tests (fast subset unless FULL=1) + bench lines; usage: run_quick.sh TAG [programs...]
+ulimit -c 0; export HSA_COREDUMP_PATTERN=/dev/null
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-q}; shift
 O=$R/gpurun_out/$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: sweep.sh TAG PROGRAM "ENV=.. ENV=.." "ENV=.." ...   → one bench line per environment setting
+ulimit -c 0; export HSA_COREDUMP_PATTERN=/dev/null
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; P=$2; shift; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R

@@ -239,6 +239,60 @@ def scatter16():
     return L
 
 
+def run_trace():
+    """k_forward2's piece: 64 chained transitions (as piece_run1) that also write the run trace.  Per step, after the
+    transition word e arrived:  head = (e != e of the previous step);  a head appends (e & 0xffff0000) | position to the
+    lane's ring of 16 entries in LDS (cnt4 = 4 x entries appended so far; a non-head stores out of range).  After every
+    8 steps a lane with 8 or more entries pending writes one 32-byte sector of them to memory (ga = byte offset of the
+    lane's trace area from tbase, fl4 = 4 x entries written out)."""
+    L = []
+    ap = L.append
+    def cls_issue(tt):
+        ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (tt >> 2, SD, tt & 3))
+        ap("ds_read_u8 %%[c%d], %%[x]" % (tt % 3))
+    for tt in (0, 1, 2):
+        cls_issue(tt)
+    ap("s_waitcnt lgkmcnt(2)")
+    ap("v_add_u32 %[x], %[h], %[c0]")
+    ap("ds_read_b32 %[e0], %[x]")
+    for j in range(64):
+        cur, nxt = "%%[e%d]" % (j & 1), "%%[e%d]" % ((j + 1) & 1)
+        if j + 3 < 64:
+            cls_issue(j + 3)
+        pend = (1 if j + 3 < 64 else 0) + (1 if j > 0 else 0)
+        ap("s_waitcnt lgkmcnt(%d)" % pend)
+        # head test against the previous step's word (still in the other register) before that register is reused
+        ap("v_cmp_ne_u32 vcc, %s, %s" % (cur, nxt))
+        if j + 1 < 64:
+            ap("v_add_u32_sdwa %%[x], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (cur, (j + 1) % 3, SD))
+            ap("ds_read_b32 %s, %%[x]" % nxt)
+        ap("v_add_u32 %%[t], %d, %%[posl]" % j)
+        ap("v_bfi_b32 %%[t], %%[cff], %%[t], %s" % cur)
+        ap("v_bfi_b32 %[ra], %[c3c], %[cnt4], %[ring]")
+        ap("v_cndmask_b32 %[ra], %[oob], %[ra], vcc")
+        ap("ds_write_b32 %[ra], %[t]")
+        ap("v_cndmask_b32 %[t], 0, %[four], vcc")
+        ap("v_add_u32 %[cnt4], %[cnt4], %[t]")
+        if j & 7 == 7:
+            ap("v_sub_u32 %[t], %[cnt4], %[fl4]")
+            ap("v_cmp_lt_u32 vcc, 31, %[t]")
+            ap("s_and_saveexec_b64 %[sv], vcc")
+            ap("s_cbranch_execz 1f")
+            ap("v_and_b32 %[t], 32, %[fl4]")
+            ap("v_add_u32 %[t], %[t], %[ring]")
+            ap("ds_read_b128 %[x0], %[t]")
+            ap("ds_read_b128 %[x1], %[t] offset:16")
+            ap("v_add_u32 %[t], %[ga], %[fl4]")
+            ap("v_add_u32 %[fl4], 32, %[fl4]")
+            ap("s_waitcnt lgkmcnt(0)")
+            ap("global_store_dwordx4 %[t], %[x0], %[tbase]")
+            ap("global_store_dwordx4 %[t], %[x1], %[tbase] offset:16")
+            ap("1:")
+            ap("s_mov_b64 exec, %[sv]")
+    ap("s_waitcnt lgkmcnt(0)")
+    return L
+
+
 def backloop():
     """k_backlen2's flat loop (programs without wide entries): every lane walks its own block backward at its own pace,
     one table access per trip.  A trip handles step p and, when the entry read is flagged E_FIXED, every step below it
@@ -287,9 +341,13 @@ def backloop():
     ap("v_cmp_lt_i32_sdwa vcc, %[p], %[qcur] src0_sel:DWORD src1_sel:WORD_0")
     ap("s_and_saveexec_b64 %[sv], vcc")
     ap("s_cbranch_execz 1f")
-    ap("s_waitcnt vmcnt(0)")
+    # the entry requested at the previous pop is in (all but the newest memory operation — a touch — must be complete);
+    # request the next one, and touch the sector two below it so that it is in L2 when its turn comes: the lanes' streams
+    # lie far apart, every first touch of a 64-byte sector is a trip to memory
+    ap("s_waitcnt vmcnt(1)")
     ap("v_sub_u32 %[qcur], %[qn], %[ceo]")      # (rows are image offsets; the tables are staged from off_ent on)
     ap("global_load_dword %[qn], %[va], %[tbase]")
+    ap("global_load_dword %[qd], %[va], %[tbase] offset:-128")
     ap("v_add_u32 %[va], -4, %[va]")
     ap("1:")
     ap("s_mov_b64 exec, %[sv]")
@@ -438,12 +496,24 @@ def main3(out):
             '"vcc", "scc", "memory"')
 
 
+def main5(out):
+    tmp = ["c0", "c1", "c2", "x", "t", "ra", "x0", "x1"]
+    emit_fn(out, "piece_run_trace",
+            "const uint32_t (&w)[16], uint32_t h, uint32_t& e0, uint32_t& e1, uint32_t posl, uint32_t& cnt4, uint32_t& fl4, uint32_t ring, uint32_t ga, unsigned long long tbase",
+            "uint32_t c0, c1, c2, x, t, ra; u32x4 x0, x1; unsigned long long sv;",
+            run_trace(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[e0] "=&v"(e0)', '[e1] "+v"(e1)', '[cnt4] "+v"(cnt4)', '[fl4] "+v"(fl4)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[h] "v"(h)', '[posl] "v"(posl)', '[ring] "v"(ring)', '[ga] "v"(ga)', '[tbase] "s"(tbase)',
+                                                               '[cff] "s"(0xffffu)', '[c3c] "s"(0x3cu)', '[oob] "v"(0x80000000u)', '[four] "v"(4u)'],
+            '"vcc", "memory"')
+
+
 def main4(out):
     emit_fn(out, "back_loop",
             "BackState& S, uint32_t plim, uint32_t ceo, unsigned long long tbase, unsigned long long pbase, unsigned long long bbase",
-            "uint32_t a, e, lo, tt, t1, t2, dl, rec, st; u32x4 x0, x1; unsigned long long sfull, sv;",
+            "uint32_t a, e, lo, tt, t1, t2, dl, rec, qd, st; u32x4 x0, x1; unsigned long long sfull, sv;",
             backloop(),
-            ['[%s] "=&v"(%s)' % (t, t) for t in ("a", "e", "lo", "tt", "t1", "t2", "dl", "rec", "x0", "x1")] +
+            ['[%s] "=&v"(%s)' % (t, t) for t in ("a", "e", "lo", "tt", "t1", "t2", "dl", "rec", "qd", "x0", "x1")] +
             ['[st] "=&s"(st)', '[sfull] "=&s"(sfull)', '[sv] "=&s"(sv)'] +
             ['[%s] "+v"(S.%s)' % (t, t) for t in ("p", "floor", "pp", "leaf", "cum", "qcur", "qn", "va", "boff", "bfl", "pb0", "kmax", "ptop", "pa", "ba")] +
             ['[tick] "+s"(S.tick)'],
@@ -457,3 +527,4 @@ if __name__ == "__main__":
     main2(sys.stdout)
     main3(sys.stdout)
     main4(sys.stdout)
+    main5(sys.stdout)

@@ -242,9 +242,9 @@ def scatter16():
 def run_trace():
     """k_forward2's piece: 64 chained transitions (as piece_run1) that also write the run trace.  Per step, after the
     transition word e arrived:  head = (e != e of the previous step);  a head appends (e & 0xffff0000) | position to the
-    lane's ring of 16 entries in LDS (cnt4 = 4 x entries appended so far; a non-head stores out of range).  After every
-    8 steps a lane with 8 or more entries pending writes one 32-byte sector of them to memory (ga = byte offset of the
-    lane's trace area from tbase, fl4 = 4 x entries written out)."""
+    lane's ring of 32 entries in LDS (cnt4 = 4 x entries appended so far; a non-head stores out of range).  After every
+    16 steps a lane with 16 or more entries pending writes one whole 64-byte sector of them to memory (ga = byte offset of
+    the lane's trace area from tbase, fl4 = 4 x entries written out): smaller writes cost the memory a read-modify-write."""
     L = []
     ap = L.append
     def cls_issue(tt):
@@ -268,25 +268,29 @@ def run_trace():
             ap("ds_read_b32 %s, %%[x]" % nxt)
         ap("v_add_u32 %%[t], %d, %%[posl]" % j)
         ap("v_bfi_b32 %%[t], %%[cff], %%[t], %s" % cur)
-        ap("v_bfi_b32 %[ra], %[c3c], %[cnt4], %[ring]")
+        ap("v_bfi_b32 %[ra], %[c7c], %[cnt4], %[ring]")
         ap("v_cndmask_b32 %[ra], %[oob], %[ra], vcc")
         ap("ds_write_b32 %[ra], %[t]")
         ap("v_cndmask_b32 %[t], 0, %[four], vcc")
         ap("v_add_u32 %[cnt4], %[cnt4], %[t]")
-        if j & 7 == 7:
+        if j & 15 == 15:
             ap("v_sub_u32 %[t], %[cnt4], %[fl4]")
-            ap("v_cmp_lt_u32 vcc, 31, %[t]")
+            ap("v_cmp_lt_u32 vcc, 63, %[t]")
             ap("s_and_saveexec_b64 %[sv], vcc")
             ap("s_cbranch_execz 1f")
-            ap("v_and_b32 %[t], 32, %[fl4]")
+            ap("v_and_b32 %[t], 64, %[fl4]")
             ap("v_add_u32 %[t], %[t], %[ring]")
             ap("ds_read_b128 %[x0], %[t]")
             ap("ds_read_b128 %[x1], %[t] offset:16")
+            ap("ds_read_b128 %[x2], %[t] offset:32")
+            ap("ds_read_b128 %[x3], %[t] offset:48")
             ap("v_add_u32 %[t], %[ga], %[fl4]")
-            ap("v_add_u32 %[fl4], 32, %[fl4]")
+            ap("v_add_u32 %[fl4], 64, %[fl4]")
             ap("s_waitcnt lgkmcnt(0)")
             ap("global_store_dwordx4 %[t], %[x0], %[tbase]")
             ap("global_store_dwordx4 %[t], %[x1], %[tbase] offset:16")
+            ap("global_store_dwordx4 %[t], %[x2], %[tbase] offset:32")
+            ap("global_store_dwordx4 %[t], %[x3], %[tbase] offset:48")
             ap("1:")
             ap("s_mov_b64 exec, %[sv]")
     ap("s_waitcnt lgkmcnt(0)")
@@ -341,13 +345,9 @@ def backloop():
     ap("v_cmp_lt_i32_sdwa vcc, %[p], %[qcur] src0_sel:DWORD src1_sel:WORD_0")
     ap("s_and_saveexec_b64 %[sv], vcc")
     ap("s_cbranch_execz 1f")
-    # the entry requested at the previous pop is in (all but the newest memory operation — a touch — must be complete);
-    # request the next one, and touch the sector two below it so that it is in L2 when its turn comes: the lanes' streams
-    # lie far apart, every first touch of a 64-byte sector is a trip to memory
-    ap("s_waitcnt vmcnt(1)")
+    ap("s_waitcnt vmcnt(0)")
     ap("v_sub_u32 %[qcur], %[qn], %[ceo]")      # (rows are image offsets; the tables are staged from off_ent on)
     ap("global_load_dword %[qn], %[va], %[tbase]")
-    ap("global_load_dword %[qd], %[va], %[tbase] offset:-128")
     ap("v_add_u32 %[va], -4, %[va]")
     ap("1:")
     ap("s_mov_b64 exec, %[sv]")
@@ -497,14 +497,14 @@ def main3(out):
 
 
 def main5(out):
-    tmp = ["c0", "c1", "c2", "x", "t", "ra", "x0", "x1"]
+    tmp = ["c0", "c1", "c2", "x", "t", "ra", "x0", "x1", "x2", "x3"]
     emit_fn(out, "piece_run_trace",
             "const uint32_t (&w)[16], uint32_t h, uint32_t& e0, uint32_t& e1, uint32_t posl, uint32_t& cnt4, uint32_t& fl4, uint32_t ring, uint32_t ga, unsigned long long tbase",
-            "uint32_t c0, c1, c2, x, t, ra; u32x4 x0, x1; unsigned long long sv;",
+            "uint32_t c0, c1, c2, x, t, ra; u32x4 x0, x1, x2, x3; unsigned long long sv;",
             run_trace(),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[e0] "=&v"(e0)', '[e1] "+v"(e1)', '[cnt4] "+v"(cnt4)', '[fl4] "+v"(fl4)'],
             ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[h] "v"(h)', '[posl] "v"(posl)', '[ring] "v"(ring)', '[ga] "v"(ga)', '[tbase] "s"(tbase)',
-                                                               '[cff] "s"(0xffffu)', '[c3c] "s"(0x3cu)', '[oob] "v"(0x80000000u)', '[four] "v"(4u)'],
+                                                               '[cff] "s"(0xffffu)', '[c7c] "s"(0x7cu)', '[oob] "v"(0x80000000u)', '[four] "v"(4u)'],
             '"vcc", "memory"')
 
 

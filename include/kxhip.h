@@ -55,7 +55,7 @@ typedef struct kx_stats {
   uint32_t fail_stage;
   uint32_t unsynced_segments;   /* segments whose start state had to be chained sequentially */
   uint64_t in_bytes, out_bytes;
-  float kernel_ms[KX_NKERNELS]; /* HIP-event time of each kernel group (last stage run)      */
+  float kernel_ms[KX_NKERNELS]; /* HIP-event time of each kernel group, summed over the stages  */
   float total_ms;               /* first launch → last kernel done, all stages               */
   uint32_t emit_overflow_pieces; /* output stage: pieces that needed a second sweep (last stage run) */
 } kx_stats;
@@ -70,6 +70,9 @@ typedef struct kx_config {
 } kx_config;
 
 int kx_load(const void* blob, size_t blob_len, kx_program** prog);
+/* Structural check of a blob without touching a device: every section inside the blob, every index inside its table,
+ * the engine's size limits.  0 or KX_E_BLOB (kx_load performs the same checks). */
+int kx_validate(const void* blob, size_t blob_len);
 void kx_free(kx_program* prog);
 const char* kx_last_error(void);
 int kx_set_config(kx_program* prog, const kx_config* cfg);

@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
   }
   uint64_t bl, dl;
   memcpy(&bl, trailer, 8); memcpy(&dl, trailer + 8, 8);
+  if (bl < 20 || bl > (uint64_t)size || dl > (uint64_t)size || bl + dl + 24 > (uint64_t)size) { fprintf(stderr, "%s: corrupt payload trailer\n", argv[0]); return 1; }
   std::vector<unsigned char> blob(bl);
   std::string libdir(dl, '\0');
   fseek(self, size - 24 - (long)dl - (long)bl, SEEK_SET);
@@ -58,6 +59,7 @@ int main(int argc, char** argv) {
     switch (c) {
       case 'i': {
         uint32_t il; memcpy(&il, blob.data() + 16, 4);
+        if ((uint64_t)il + 20 > blob.size()) { fprintf(stderr, "%s: corrupt payload\n", argv[0]); return 1; }
         std::string info((const char*)blob.data() + 20, il);
         for (size_t p; (p = info.find("\\n")) != std::string::npos;) info.replace(p, 2, "\n");
         fprintf(stdout, "%s\n", info.c_str());

@@ -225,6 +225,9 @@ struct Parser {
   RegexP regexConcat() {
     RegexP acc;
     while (!eof() && peek() != '/' && peek() != '|' && peek() != ')') {
+      // an unescaped '$' that closes the literal is the end anchor (anchoredRegexP, Parser.hs:204-206, strips both
+      // anchors: Kleenex terms are anchored anyway), not a byte to match
+      if (peek() == '$' && p + 1 < s.size() && s[p + 1] == '/') { ++p; break; }
       RegexP r = regexRepeat();
       acc = acc ? mk2(Regex::Concat, acc, r) : r;
     }

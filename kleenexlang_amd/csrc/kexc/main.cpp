@@ -14,7 +14,10 @@
 //   --backend=c              reference-shaped C piped to `cc -O3 -xc -o BIN
 //                            "-D FLAG_WORDALIGNED" -` exactly as C.hs:556-568
 //                            does; needs --crt-dir (directory holding crt.c).
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <unistd.h>
 
 #include <climits>
@@ -98,11 +101,30 @@ int main(int argc, char** argv) {
       if (!o.srcout.empty()) { std::ofstream f(o.srcout); f << txt; }
       if (o.out.empty()) return 0;
       if (crtdir.empty()) { std::cerr << "--backend=c needs --crt-dir DIR (directory with crt.c)\n"; return 1; }
-      std::string cmd = o.cc + " -O" + std::to_string(o.copt) + " -xc -o '" + o.out + "' -w \"-D FLAG_WORDALIGNED\" -I'" + crtdir + "' -";
-      FILE* p = popen(cmd.c_str(), "w");
-      if (!p) { std::cerr << "cannot run " << o.cc << "\n"; return 1; }
-      fwrite(txt.data(), 1, txt.size(), p);
-      int rc = pclose(p);
+      // cc -O<copt> -xc -o <out> "-D FLAG_WORDALIGNED" -, source on stdin (C.hs:556-568).  fork/exec with an argument
+      // vector: no shell ever sees --out, --crt-dir or --cc.
+      const std::string optflag = "-O" + std::to_string(o.copt), incflag = "-I" + crtdir;
+      const char* av[] = {o.cc.c_str(), optflag.c_str(), "-xc", "-o", o.out.c_str(), "-w", "-D FLAG_WORDALIGNED", incflag.c_str(), "-", nullptr};
+      int fds[2];
+      if (pipe(fds)) { std::cerr << "cannot run " << o.cc << "\n"; return 1; }
+      pid_t pid = fork();
+      if (pid < 0) { std::cerr << "cannot run " << o.cc << "\n"; return 1; }
+      if (pid == 0) {
+        dup2(fds[0], STDIN_FILENO); close(fds[0]); close(fds[1]);
+        execvp(av[0], const_cast<char* const*>(av));
+        std::cerr << "cannot run " << o.cc << "\n";
+        _exit(127);
+      }
+      close(fds[0]);
+      signal(SIGPIPE, SIG_IGN);
+      for (size_t off = 0; off < txt.size();) {
+        ssize_t w = write(fds[1], txt.data() + off, txt.size() - off);
+        if (w <= 0) break;
+        off += (size_t)w;
+      }
+      close(fds[1]);
+      int rc = 0;
+      waitpid(pid, &rc, 0);
       return WIFEXITED(rc) ? WEXITSTATUS(rc) : 1;
     }
     if (o.backend != "hip") { std::cerr << "unknown backend " << o.backend << "\n"; return 1; }

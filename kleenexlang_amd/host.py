@@ -112,6 +112,7 @@ def load_engine():
         lib = ctypes.CDLL(path)
         vp, sz, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
         lib.kx_load.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+        lib.kx_validate.argtypes = [ctypes.c_char_p, sz]
         lib.kx_free.argtypes = [vp]
         lib.kx_last_error.restype = ctypes.c_char_p
         lib.kx_set_config.argtypes = [vp, ctypes.POINTER(KxConfig)]
@@ -183,6 +184,14 @@ def dump_fst(source, name="<memory>"):
         return json.loads(ctypes.string_at(txt, n.value).decode("utf-8"))
     finally:
         lib.kexc_free(txt)
+
+
+def validate_blob(blob):
+    """Structural check of a KXP blob (no device needed).  Raises EngineError with the engine's message."""
+    lib = load_engine()
+    blob = bytes(blob)
+    if lib.kx_validate(blob, len(blob)):
+        raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
 
 
 def program_path(name):

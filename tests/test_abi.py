@@ -46,3 +46,45 @@ def test_engine_refuses_to_run_without_a_gpu():
     from kleenexlang_amd import EngineError, Program, compile_file
     with pytest.raises(EngineError, match="no HIP device|HIP"):
         Program(compile_file("flip_ab"))
+
+
+def test_corrupt_and_truncated_blobs_are_refused_not_read_out_of_bounds():
+    """every section and index of a blob is validated before use (kx_validate = the checks of kx_load,
+    without a device).  Truncations at every length and a few thousand single-field corruptions must give an error
+    or, where the change is harmless, a clean pass — never a crash."""
+    import random
+    import struct
+    import pytest
+    from kleenexlang_amd import EngineError, compile_file, host
+    for name in ("flip_ab", "csv2json", "apache_log"):
+        blob = compile_file(name)
+        host.validate_blob(blob)                         # the real thing passes
+        step = max(1, len(blob) // 400)
+        for cut in list(range(0, 200)) + list(range(200, len(blob) - 1, step)):
+            with pytest.raises(EngineError):
+                host.validate_blob(blob[:cut])
+        r = random.Random(7)
+        hdr = 20 + ((struct.unpack_from("<I", blob, 16)[0] + 3) & ~3)
+        refused = 0
+        for _ in range(1500):
+            b = bytearray(blob)
+            off = hdr + (r.randrange(0, 16) * 4 if r.random() < 0.3 else r.randrange(0, len(blob) - hdr - 4) & ~3)
+            struct.pack_into("<I", b, off, r.choice([0xFFFFFFFF, 0x7FFFFFFF, 0x10000, r.getrandbits(32)]))
+            try:
+                host.validate_blob(bytes(b))
+            except EngineError:
+                refused += 1
+        assert refused > 100, refused
+
+
+def test_produced_binary_refuses_a_corrupt_trailer(tmp_path):
+    import subprocess as sp
+    from kleenexlang_amd import program_path
+    exe = tmp_path / "flip"
+    assert sp.run([os.path.join(build.OUT, "kexc"), "compile", "--quiet", program_path("flip_ab"), "--out", str(exe)]).returncode == 0
+    data = bytearray(exe.read_bytes())
+    data[-24:-16] = (1 << 40).to_bytes(8, "little")      # blob length far beyond the file
+    bad = tmp_path / "bad"
+    bad.write_bytes(bytes(data)); bad.chmod(0o755)
+    r = sp.run([str(bad), "-i"], stdout=sp.PIPE, stderr=sp.PIPE)
+    assert r.returncode == 1 and b"corrupt" in r.stderr

@@ -73,3 +73,28 @@ def test_slash_inside_a_character_class_does_not_end_the_regex():
     from conftest import blob_of
     blob = blob_of('main := (/[a-c: /+-]+/ "." | ~/;/)*\n')
     assert oracle.run(blob, b"a/b;c+-;: /") == b"a/b.c+-.: /."
+
+
+def test_trailing_dollar_is_the_end_anchor_not_a_byte():
+    """anchoredRegexP (Parser.hs:204-206) strips '^' and '$'; `main := /abc$/` must accept "abc", and an
+    escaped dollar stays a literal byte."""
+    from kleenexlang_amd import compile_source
+    from oracle import oracle
+    assert oracle.run(compile_source("main := /^abc$/\n"), b"abc") == b"abc"
+    with pytest.raises(oracle.OracleMatchError):
+        oracle.run(compile_source("main := /abc$/\n"), b"abc$")
+    assert oracle.run(compile_source("main := /abc\\$/\n"), b"abc$") == b"abc$"
+    assert oracle.run(compile_source("main := /a$b/\n"), b"a$b") == b"a$b"     # not at the end: a byte
+
+
+def test_backend_c_paths_with_quotes_and_spaces_never_reach_a_shell(tmp_path):
+    d = tmp_path / "dir with 'quote' and $(touch pwned)"
+    d.mkdir()
+    out = d / "bin'ary"
+    crt = os.path.join(build.ROOT, "oracle", "crt_port")
+    r = subprocess.run([KEXC, "compile", "--quiet", "--backend=c", "--crt-dir", crt, program_path("flip_ab"), "--out", str(out)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert not (tmp_path / "pwned").exists()
+    r = subprocess.run([str(out)], input=b"abba\n", stdout=subprocess.PIPE)
+    assert r.stdout == b"baab\n"

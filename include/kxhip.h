@@ -65,7 +65,7 @@ typedef struct kx_config {
   uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; 0 = one round of lanes (4-64 KiB)  */
   uint32_t block_threads;  /* workgroup size (power of two); default 512        */
   uint32_t collect_timing; /* record per-kernel HIP events into kx_stats        */
-  uint32_t pad;
+  uint32_t phase;          /* kx_run_fd: 0 = the whole pipeline; K = only phase K, stdin -> stdout (`BIN --phase K`, crt/crt.c:390-393,408-411) */
   uint64_t window_bytes;   /* kx_run_fd: input bytes resident at a time; 0 = 4 GiB (env KX_WINDOW_BYTES overrides) */
 } kx_config;
 

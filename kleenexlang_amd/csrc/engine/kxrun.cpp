@@ -4,10 +4,10 @@
 // (crt/crt.c:326-467): `BIN < in > out`; `-i` prints compile info and exits 2;
 // `-t` prints "time (ms): N" on stderr; `-h`/unknown prints usage on stdout and
 // exits 1; a rejected input prints "Match error at input symbol <count>!" on
-// stderr and exits 1.  `-p/--phase K` is accepted for compatibility: the phases
-// of a pipeline run as chained device-resident stages inside one process
-// (instead of fork()+pipe(), crt.c:414-454), so a single phase cannot be
-// selected.
+// stderr and exits 1.  `-p/--phase K` runs only phase K, stdin to stdout, as in
+// the reference (crt.c:390-393,408-411); without it the phases of a pipeline run
+// as chained device-resident stages inside one process (instead of
+// fork()+pipe(), crt.c:414-454).
 //
 // BIN = this executable ++ KXP blob ++ libdir ++ trailer (see kexc main.cpp).
 // The engine is loaded with dlopen so that this file carries no HIP dependency.
@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
 
   static struct option long_options[] = {{"phase", required_argument, 0, 'p'}, {0, 0, 0, 0}};
   bool timing = false;
+  long phase = 0;
   int c;
   while ((c = getopt_long(argc, argv, "ihtp:", long_options, nullptr)) != -1) {
     switch (c) {
@@ -66,7 +67,7 @@ int main(int argc, char** argv) {
         return 2;
       }
       case 't': timing = true; break;
-      case 'p': break;
+      case 'p': phase = atol(optarg); if (phase < 1) { fprintf(stderr, "Invalid phase: %ld given\n", phase); return 1; } break;
       case 'h':
       default: usage(argv[0]); return 1;
     }
@@ -84,6 +85,15 @@ int main(int argc, char** argv) {
   if (!load || !run || !lasterr) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
   kx_program* prog = nullptr;
   if (load(blob.data(), blob.size(), &prog)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
+  if (phase) {
+    auto setcfg = (int (*)(kx_program*, const kx_config*))dlsym(h, "kx_set_config");
+    auto nst = (uint32_t (*)(const kx_program*))dlsym(h, "kx_num_stages");
+    if (!setcfg || !nst) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
+    if ((unsigned long)phase > nst(prog)) { fprintf(stderr, "Invalid phase: %ld given\n", phase); return 1; }   // (crt.c match(): default case)
+    kx_config cfg{};
+    cfg.phase = (uint32_t)phase;
+    if (setcfg(prog, &cfg)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
+  }
   kx_stats st;
   int rc = run(prog, STDIN_FILENO, STDOUT_FILENO, &st);
   if (rc == KX_MATCH_ERROR) { fprintf(stderr, "Match error at input symbol %zu!\n", (size_t)st.fail_pos); return 1; }

@@ -55,7 +55,7 @@ class KxStats(ctypes.Structure):
 
 class KxConfig(ctypes.Structure):
     _fields_ = [("segment_bytes", ctypes.c_uint32), ("block_threads", ctypes.c_uint32),
-                ("collect_timing", ctypes.c_uint32), ("pad", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
+                ("collect_timing", ctypes.c_uint32), ("phase", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
 
 
 class KxFwdSummary(ctypes.Structure):

@@ -342,3 +342,45 @@ def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
         line = json.loads([x for x in r.stdout.decode().splitlines() if x.startswith('{"metric"')][-1])
         assert line["n_gpus"] == world and line["config"]["boundary_backend"] == "nccl"
         assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]
+
+
+def test_never_merging_program_resolves_in_linear_work():
+    """a program whose surviving path is only decided by the LAST byte never lets the blocks'
+    candidates merge; the end leaves are then resolved by one backward pass over the blocks (k_resolve_leaf), not by
+    a walk per block.  16 Ki blocks here; both outcomes."""
+    src = 'main := /[ab]*/ "!" | /[ab]*/ ~/c/ "?"\n'
+    blob = blob_of(src)
+    rnd = random.Random(5)
+    body = bytes(rnd.choice(b"ab") for _ in range(1 << 16)) * 256          # 16 MiB
+    for tail, mark in ((b"", b"!"), (b"c", b"?")):
+        data = body + tail
+        p = Program(blob, segment_bytes=1024)
+        got = p.run_host(data)
+        assert got == body + mark
+        p.close()
+    small = body[:5000] + b"c"
+    got, want = both(blob, small, segment_bytes=64)
+    assert got == want == body[:5000] + b"?"
+
+
+def test_phase_option_runs_one_stage_of_a_pipeline(tmp_path):
+    """`BIN --phase K` runs only phase K, stdin -> stdout (crt/crt.c:390-393,408-411): piping phase 1 into phase 2 by hand
+    equals the whole pipeline; an invalid phase gives the reference's message and exit 1."""
+    import subprocess
+    from kleenexlang_amd import build
+    kexc = os.path.join(build.OUT, "kexc")
+    src = ('start: commas >> brackets\n'
+           'commas := (num /\\n/)*\nnum := digit{1,3} ("," digit{3})*\ndigit := /[0-9]/\n'
+           'brackets := (/[0-9]+/ "<" | /,/ ">" | /\\n/)*\n')
+    path = tmp_path / "two.kex"; path.write_text(src)
+    exe = tmp_path / "two"
+    assert subprocess.run([kexc, "compile", "--quiet", str(path), "--out", str(exe)]).returncode == 0
+    data = workloads.generate("numbers", 50000, 4)
+    whole = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE).stdout
+    assert whole == oracle.run(blob_of(src), data)
+    p1 = subprocess.run([str(exe), "--phase", "1"], input=data, stdout=subprocess.PIPE).stdout
+    assert p1 != whole and b"," in p1 and b"<" not in p1
+    p2 = subprocess.run([str(exe), "-p", "2"], input=p1, stdout=subprocess.PIPE).stdout
+    assert p2 == whole
+    r = subprocess.run([str(exe), "--phase", "3"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Invalid phase: 3 given" in r.stderr

@@ -9,16 +9,72 @@
  * There the `Pipeline` of IL programs is printed as C and piped to `cc`; here
  * the same information leaves the compiler as a KXP table blob
  * (include/kxp_format.h) that the HIP engine (include/kxhip.h) loads.
- * Because no Haskell toolchain exists in this environment the front half
- * (Kleenex source → SST) is restated in C++ behind the same ABI, so the entry
- * point takes source text rather than a marshalled `Pipeline`.
+ * Two entries: kexc_emit_pipeline is compileProgram itself — a front end that has its own SSTs (the reference's
+ * Haskell one) marshals its `Pipeline` into tables and calls it with compileProgram's argument list, one to one;
+ * kexc_compile puts the restated front half (Kleenex source → SST, C++: no Haskell toolchain exists in this
+ * environment) in front of the same back end.
  */
 #ifndef KEXC_API_H
 #define KEXC_API_H
 #include <stddef.h>
+#include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* One IL `Program` (src/KMC/Program/IL.hs:69-88) of a `--la=false` pipeline in table form, plus the path-tree annotation.
+ *
+ * With `--la=false` every block is `NextI 1 1 fallback ; [IfI (avail>=1 && pred_j(next[0])) (updates_j ++ [ConsumeI 1,
+ * GotoI s_j])]_j ; FailI` with pairwise disjoint predicates (SSTCompiler.hs:138-156), i.e. a table:
+ *   class_of      coarsest partition of all test predicates (byte -> class)
+ *   delta/action  per (block, class): GotoI target (0xFFFF = FailI) and the register updates, as an index into `actions`
+ *   final_action  the NextI fallback: updates then AcceptI; 0xFFFFFFFF = FailI
+ *   actions       ordered micro-ops {op << 24 | dst register, arg}: 0 ResetI dst; 1 AppendI dst, constant arg;
+ *                 2 AppendSymI dst (the current input byte); 3 ConcatI dst, register arg      (IL.hs:40-47; register 0 =
+ *                 progStreamBuffer, the output)
+ *   constants     progConstants as offsets into one pool (const_off[nconsts+1])
+ * The annotation is what the determinizer knows when it builds a transition (Determinization.hs:165-177, TreeWriter.hs)
+ * and the IL no longer says: which leaf of the SOURCE state's path tree each leaf of the TARGET state extends, and by
+ * what.  It lets the engine replace the registers by a backward pass:
+ *   nleaves[q], final_leaf[q] (0xFF = not final), maxleaves
+ *   back_row[block*nclasses+class] -> row of `back`; back[row*maxleaves + leaf] = parent leaf | copies input byte << 8 |
+ *                 path constant << 9 (0xFFFFFFFF = leaf does not exist); path constants as offsets into a second pool
+ *   init_const[leaf] path constant emitted by the initial closure on each leaf of the start state */
+typedef struct kexc_il_program {
+  uint32_t nstates, nclasses, init_state, nregs;
+  const uint8_t* class_of;        /* [256] */
+  const uint16_t* delta;          /* [nstates*nclasses] */
+  const uint32_t* action;         /* [nstates*nclasses] */
+  const uint32_t* final_action;   /* [nstates] */
+  uint32_t nactions; const uint32_t* action_off; const uint32_t* ops;   /* action_off[nactions+1]; ops[2*nops] */
+  uint32_t nconsts; const uint32_t* const_off; const uint8_t* const_pool;
+  uint32_t maxleaves, nback;
+  const uint32_t* back_row;       /* [nstates*nclasses] */
+  const uint8_t* nleaves; const uint8_t* final_leaf;   /* [nstates] */
+  const uint32_t* back;           /* [nback*maxleaves] */
+  uint32_t npconsts; const uint32_t* pconst_off; const uint8_t* pconst_pool;
+  const uint32_t* init_const;     /* [maxleaves] */
+} kexc_il_program;
+
+/* `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per
+ * program; Right = (oracle, action) pairs, programs[2i] and programs[2i+1] — accepted by the type, refused by this
+ * build (register actions are not executed on the device yet). */
+typedef struct kexc_pipeline { int is_oracle_action; uint32_t nprograms; const kexc_il_program* programs; } kexc_pipeline;
+
+/* compileProgram (src/KMC/Program/Backends/C.hs:529-540), argument for argument:
+ *   CType buffer unit        -> buffer_unit_bits (8; 16/32/64 are refused: `--wordsize` other than 8 is not built)
+ *   Int cc -O level          -> cc_opt_level     (no C compiler runs for the HIP back end: accepted, unused)
+ *   String -> m () info      -> info(line, ctx)  (called with the progress line the reference prints, C.hs:553)
+ *   Pipeline                 -> pipeline
+ *   Maybe String             -> env_info         (text that `BIN -i` prints; NULL = Nothing)
+ *   FilePath cc              -> cc               (accepted, unused)
+ *   Maybe FilePath binary    -> out_path         (NULL = Nothing: like the reference, only srcout is written then)
+ *   Maybe FilePath source    -> srcout_path      (the KXP blob is this back end's "source")
+ *   Bool word alignment      -> word_alignment   (accepted, unused: the device output is a byte stream)
+ * Returns the exit code (0 = ExitSuccess); on failure the message is in kexc_last_error(). */
+int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(const char* line, void* ctx), void* info_ctx,
+                       const kexc_pipeline* pipeline, const char* env_info, const char* cc, const char* out_path,
+                       const char* srcout_path, int word_alignment);
 
 /* Compile Kleenex source text (direct mode, --la=false semantics) to a KXP blob.
  * opt_level = the reference's `--opt` (0..3, SymbolicSST.optimize).

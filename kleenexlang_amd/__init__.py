@@ -6,7 +6,7 @@ for gfx950 behind a C ABI (include/kxhip.h), plus the compiler restatement neede
 obtain transducers at all (include/kexc_api.h).  See DESIGN.md.
 """
 from .host import (CompileError, EngineError, KleenexError, MatchError, Program, compile_file,  # noqa: F401
-                   compile_source, emit_c, program_path)
+                   compile_source, emit_c, emit_pipeline, program_path)
 
-__all__ = ["Program", "compile_source", "compile_file", "emit_c", "program_path",
+__all__ = ["Program", "compile_source", "compile_file", "emit_c", "emit_pipeline", "program_path",
            "KleenexError", "CompileError", "EngineError", "MatchError"]

@@ -49,9 +49,9 @@ def build_kexc(force=False):
     lib = os.path.join(OUT, "libkexc.so")
     exe = os.path.join(OUT, "kexc")
     if force or _newer(lib, deps):
-        _run(["g++", *CXXFLAGS, "-shared", "-o", lib, *srcs])
+        _run(["g++", *CXXFLAGS, "-shared", "-o", lib, *srcs, "-ldl"])
     if force or _newer(exe, deps):
-        _run(["g++", *CXXFLAGS, "-o", exe, os.path.join(CSRC, "kexc", "main.cpp"), *srcs])
+        _run(["g++", *CXXFLAGS, "-o", exe, os.path.join(CSRC, "kexc", "main.cpp"), *srcs, "-ldl"])
     return lib, exe
 
 

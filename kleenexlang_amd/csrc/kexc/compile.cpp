@@ -3,7 +3,11 @@
 // Mirrors the direct-mode compile path of the reference:
 //   createProgram → buildTransducers → generateDirectSSTs → compileDirect
 //   (src/KMC/Frontend/Commands.hs:50-68,82-115,155-180,182-210).
+#include <dlfcn.h>
+#include <sys/stat.h>
+
 #include <cstring>
+#include <fstream>
 #include <sstream>
 
 #include "../../../include/kexc_api.h"
@@ -28,6 +32,20 @@ Compiled compileSource(const std::string& src, const std::string& srcname, const
   for (size_t i = 0; i < out.sst_states.size(); ++i) info << (i ? ", " : "") << out.sst_states[i];
   out.info = info.str();
   return out;
+}
+
+void writeBinary(const std::string& out, const std::vector<uint8_t>& blob, const std::string& dir) {
+  std::ifstream drv(dir + "/kxrun", std::ios::binary);
+  if (!drv) throw CompileError("host driver not found: " + dir + "/kxrun (run __graft_entry__.build())");
+  std::ofstream bin(out, std::ios::binary | std::ios::trunc);
+  if (!bin) throw CompileError("cannot write " + out);
+  bin << drv.rdbuf();
+  bin.write((const char*)blob.data(), blob.size());
+  bin.write(dir.data(), dir.size());
+  uint64_t bl = blob.size(), dl = dir.size();
+  bin.write((const char*)&bl, 8); bin.write((const char*)&dl, 8); bin.write("KXRUNTRL", 8);
+  bin.close();
+  chmod(out.c_str(), 0755);
 }
 
 }  // namespace kexc
@@ -119,6 +137,89 @@ int kexc_dump_fst(const char* source, size_t source_len, const char* source_name
     std::string txt = o.str();
     *json = dupBytes(txt.data(), txt.size());
     *json_len = txt.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+// compileProgram's seam (Backends/C.hs:529-540) for callers that bring their own SSTs: the Pipeline arrives as tables.
+int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(const char* line, void* ctx), void* info_ctx,
+                       const kexc_pipeline* pl, const char* env_info, const char* cc, const char* out_path,
+                       const char* srcout_path, int word_alignment) {
+  (void)cc_opt_level; (void)cc; (void)word_alignment;   // meaningful to a C compiler only; kept so that the argument list stays one-to-one
+  try {
+    using namespace kexc;
+    if (!pl || !pl->programs || pl->nprograms == 0) throw CompileError("empty pipeline");
+    if (buffer_unit_bits != 8) throw CompileError("buffer unit must be 8 bits (UInt8T): the engine's output is a byte stream (--wordsize 8)");
+    if (pl->is_oracle_action) throw CompileError("oracle/action pipelines (Right [(Program, Program)]) are not executable yet: compile with --act=false");
+    std::vector<StageTables> stages;
+    for (uint32_t pi = 0; pi < pl->nprograms; ++pi) {
+      const kexc_il_program& P = pl->programs[pi];
+      auto bad = [&](const std::string& what) { throw CompileError("program " + std::to_string(pi) + ": " + what); };
+      if (!P.nstates || P.nstates >= 0xFFFF || !P.nclasses || P.nclasses > 256 || P.init_state >= P.nstates) bad("state/class counts out of range");
+      if (!P.maxleaves || P.maxleaves > 254) bad("maxleaves out of range");
+      if (!P.class_of || !P.delta || !P.action || !P.final_action || !P.action_off || !P.const_off || !P.back_row || !P.nleaves || !P.final_leaf ||
+          !P.back || !P.pconst_off || !P.init_const) bad("missing table");
+      StageTables t;
+      t.nstates = (int)P.nstates; t.nclasses = (int)P.nclasses; t.q0 = (int)P.init_state; t.nregs = (int)P.nregs; t.maxleaves = (int)P.maxleaves;
+      const size_t sc = (size_t)P.nstates * P.nclasses;
+      for (int b = 0; b < 256; ++b) { if (P.class_of[b] >= P.nclasses) bad("byte class out of range"); t.cls[b] = P.class_of[b]; }
+      t.delta.assign(P.delta, P.delta + sc); t.act.assign(P.action, P.action + sc); t.final_act.assign(P.final_action, P.final_action + P.nstates);
+      t.pback.assign(P.back_row, P.back_row + sc);
+      for (uint32_t c = 0; c < P.nconsts; ++c) {
+        if (P.const_off[c + 1] < P.const_off[c]) bad("constant offsets out of order");
+        t.consts.emplace_back((const char*)P.const_pool + P.const_off[c], P.const_off[c + 1] - P.const_off[c]);
+      }
+      for (uint32_t c = 0; c < P.npconsts; ++c) {
+        if (P.pconst_off[c + 1] < P.pconst_off[c]) bad("path constant offsets out of order");
+        t.pconsts.emplace_back((const char*)P.pconst_pool + P.pconst_off[c], P.pconst_off[c + 1] - P.pconst_off[c]);
+      }
+      for (uint32_t a = 0; a < P.nactions; ++a) {
+        if (P.action_off[a + 1] < P.action_off[a]) bad("action offsets out of order");
+        std::vector<MicroOp> ops;
+        for (uint32_t k = P.action_off[a]; k < P.action_off[a + 1]; ++k) {
+          const uint32_t w0 = P.ops[2 * k], arg = P.ops[2 * k + 1], op = w0 >> 24, dst = w0 & 0xFFFFFF;
+          if (op > 3 || dst >= P.nregs || (op == 1 && arg >= P.nconsts) || (op == 3 && arg >= P.nregs)) bad("malformed micro-op");
+          ops.push_back(MicroOp{(uint8_t)op, (uint16_t)dst, arg});
+        }
+        t.actions.push_back(ops);
+      }
+      for (size_t i = 0; i < sc; ++i) {
+        if (t.delta[i] == 0xFFFF) continue;
+        if (t.delta[i] >= P.nstates || t.act[i] >= P.nactions || t.pback[i] >= P.nback) bad("transition out of range");
+      }
+      for (uint32_t q = 0; q < P.nstates; ++q) {
+        if (t.final_act[q] != 0xFFFFFFFFu && t.final_act[q] >= P.nactions) bad("final action out of range");
+        if (P.nleaves[q] == 0 || P.nleaves[q] > P.maxleaves || (P.final_leaf[q] != 0xFF && P.final_leaf[q] >= P.nleaves[q])) bad("leaf counts out of range");
+        if ((t.final_act[q] == 0xFFFFFFFFu) != (P.final_leaf[q] == 0xFF)) bad("final action and final leaf disagree");
+      }
+      t.nleaves.assign(P.nleaves, P.nleaves + P.nstates); t.fin_leaf.assign(P.final_leaf, P.final_leaf + P.nstates);
+      t.back.assign(P.back, P.back + (size_t)P.nback * P.maxleaves);
+      for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= P.npconsts)) bad("backward entry out of range");
+      t.init_const.assign(P.init_const, P.init_const + P.maxleaves);
+      for (uint32_t v : t.init_const) if (v >= P.npconsts) bad("initial constant out of range");
+      buildSync(t);
+      stages.push_back(std::move(t));
+    }
+    const std::string infotxt = env_info ? env_info : "";
+    std::vector<uint8_t> blob = writeBlob(stages, infotxt);
+    if (info) {   // the reference reports the size of what it generated (C.hs:553)
+      const std::string line = "Generated a KXP table blob of " + std::to_string(blob.size()) + " bytes (" + std::to_string(stages.size()) + " phase(s)).";
+      info(line.c_str(), info_ctx);
+    }
+    if (srcout_path && *srcout_path) {
+      std::ofstream f(srcout_path, std::ios::binary | std::ios::trunc);
+      if (!f) throw CompileError(std::string("cannot write ") + srcout_path);
+      f.write((const char*)blob.data(), blob.size());
+    }
+    if (out_path && *out_path) {
+      Dl_info di;
+      std::string dir = ".";
+      if (dladdr((const void*)&kexc_emit_pipeline, &di) && di.dli_fname) { dir = di.dli_fname; size_t k = dir.rfind('/'); dir = k == std::string::npos ? "." : dir.substr(0, k); }
+      writeBinary(out_path, blob, dir);
+    }
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();

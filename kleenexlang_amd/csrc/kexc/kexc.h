@@ -162,6 +162,9 @@ struct StageTables {
   bool sync_complete = true;          // false if the subset construction hit its cap
 };
 StageTables lower(const SST& s, const SST& path_src);
+void buildSync(StageTables& t);            // fills sync_next / sync_state from delta
+// BIN = kxrun ++ blob ++ libdir ++ trailer (the produced binary of `kexc compile --out BIN`); dir = where kxrun and libkxhip.so lie
+void writeBinary(const std::string& out, const std::vector<uint8_t>& blob, const std::string& dir);
 std::vector<uint8_t> writeBlob(const std::vector<StageTables>& stages, const std::string& info);
 std::string emitC(const std::vector<StageTables>& stages, const std::string& info);
 

@@ -67,6 +67,43 @@ struct Lowerer {
 
 }  // namespace
 
+// The synchronising automaton of a stage: subsets of states reachable from "any state" (what k_sync runs from a
+// segment start until one state remains).  Needs only delta, so it is also built for programs that arrive as tables
+// (kexc_emit_pipeline).
+void buildSync(StageTables& t) {
+  const size_t n = (size_t)t.nstates;
+  t.sync_next.clear(); t.sync_state.clear(); t.sync_complete = true;
+  {
+    const size_t CAP = 4096;
+    std::map<std::vector<uint16_t>, uint32_t> ids;
+    std::vector<std::vector<uint16_t>> subs;
+    auto intern = [&](const std::vector<uint16_t>& v) -> uint32_t {
+      auto it = ids.find(v);
+      if (it != ids.end()) return it->second;
+      if (subs.size() >= CAP) { t.sync_complete = false; return KXP_SYNC_UNKNOWN; }
+      uint32_t id = (uint32_t)subs.size(); ids[v] = id; subs.push_back(v); return id;
+    };
+    std::vector<uint16_t> all(n);
+    for (size_t i = 0; i < n; ++i) all[i] = (uint16_t)i;
+    intern(all);
+    for (size_t i = 0; i < subs.size(); ++i) {
+      std::vector<uint16_t> cur = subs[i];
+      t.sync_state.push_back(cur.size() == 1 ? cur[0] : cur.empty() ? KXP_SYNC_EMPTY : KXP_SYNC_MULTI);
+      for (int c = 0; c < t.nclasses; ++c) {
+        uint32_t nx;
+        if (cur.size() <= 1) nx = (uint32_t)i;  // terminal for the engine (singleton / empty)
+        else {
+          std::vector<uint16_t> v;
+          for (uint16_t q : cur) { uint16_t d = t.delta[(size_t)q * t.nclasses + c]; if (d != KXP_NO_STATE) v.push_back(d); }
+          std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+          nx = intern(v);
+        }
+        t.sync_next.push_back(nx);
+      }
+    }
+  }
+}
+
 StageTables lower(const SST& s, const SST&) {
   StageTables t;
   size_t n = s.states.size();
@@ -161,36 +198,7 @@ StageTables lower(const SST& s, const SST&) {
   t.init_const.assign(t.maxleaves, 0);
   for (size_t j = 0; j < s.init_path.size(); ++j) t.init_const[j] = pconstId(s.init_path[j]);
 
-  // synchronising automaton: subsets of states reachable from "any state"
-  {
-    const size_t CAP = 4096;
-    std::map<std::vector<uint16_t>, uint32_t> ids;
-    std::vector<std::vector<uint16_t>> subs;
-    auto intern = [&](const std::vector<uint16_t>& v) -> uint32_t {
-      auto it = ids.find(v);
-      if (it != ids.end()) return it->second;
-      if (subs.size() >= CAP) { t.sync_complete = false; return KXP_SYNC_UNKNOWN; }
-      uint32_t id = (uint32_t)subs.size(); ids[v] = id; subs.push_back(v); return id;
-    };
-    std::vector<uint16_t> all(n);
-    for (size_t i = 0; i < n; ++i) all[i] = (uint16_t)i;
-    intern(all);
-    for (size_t i = 0; i < subs.size(); ++i) {
-      std::vector<uint16_t> cur = subs[i];
-      t.sync_state.push_back(cur.size() == 1 ? cur[0] : cur.empty() ? KXP_SYNC_EMPTY : KXP_SYNC_MULTI);
-      for (int c = 0; c < t.nclasses; ++c) {
-        uint32_t nx;
-        if (cur.size() <= 1) nx = (uint32_t)i;  // terminal for the engine (singleton / empty)
-        else {
-          std::vector<uint16_t> v;
-          for (uint16_t q : cur) { uint16_t d = t.delta[(size_t)q * t.nclasses + c]; if (d != KXP_NO_STATE) v.push_back(d); }
-          std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
-          nx = intern(v);
-        }
-        t.sync_next.push_back(nx);
-      }
-    }
-  }
+  buildSync(t);
   return t;
 }
 

@@ -133,18 +133,7 @@ int main(int argc, char** argv) {
     if (!o.srcout.empty()) { std::ofstream f(o.srcout, std::ios::binary); f.write((const char*)blob.data(), blob.size()); }
     if (o.out.empty()) return 0;
     // BIN = kxrun ++ blob ++ libdir ++ trailer{blob_len u64, libdir_len u64, "KXRUNTRL"}
-    std::string dir = selfDir();
-    std::ifstream drv(dir + "/kxrun", std::ios::binary);
-    if (!drv) { std::cerr << "host driver not found: " << dir << "/kxrun (run __graft_entry__.build())\n"; return 1; }
-    std::ofstream bin(o.out, std::ios::binary | std::ios::trunc);
-    if (!bin) { std::cerr << "cannot write " << o.out << "\n"; return 1; }
-    bin << drv.rdbuf();
-    bin.write((const char*)blob.data(), blob.size());
-    bin.write(dir.data(), dir.size());
-    uint64_t bl = blob.size(), dl = dir.size();
-    bin.write((const char*)&bl, 8); bin.write((const char*)&dl, 8); bin.write("KXRUNTRL", 8);
-    bin.close();
-    chmod(o.out.c_str(), 0755);
+    writeBinary(o.out, blob, selfDir());
     return 0;
   } catch (const CompileError& e) {
     std::cerr << e.what() << "\n";

@@ -194,6 +194,53 @@ def validate_blob(blob):
         raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
 
 
+class KexcIlProgram(ctypes.Structure):
+    """include/kexc_api.h::kexc_il_program — one IL Program in table form + the path-tree annotation."""
+    _u8p, _u16p, _u32p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint32)
+    _fields_ = [("nstates", ctypes.c_uint32), ("nclasses", ctypes.c_uint32), ("init_state", ctypes.c_uint32), ("nregs", ctypes.c_uint32),
+                ("class_of", _u8p), ("delta", _u16p), ("action", _u32p), ("final_action", _u32p),
+                ("nactions", ctypes.c_uint32), ("action_off", _u32p), ("ops", _u32p),
+                ("nconsts", ctypes.c_uint32), ("const_off", _u32p), ("const_pool", _u8p),
+                ("maxleaves", ctypes.c_uint32), ("nback", ctypes.c_uint32), ("back_row", _u32p),
+                ("nleaves", _u8p), ("final_leaf", _u8p), ("back", _u32p),
+                ("npconsts", ctypes.c_uint32), ("pconst_off", _u32p), ("pconst_pool", _u8p), ("init_const", _u32p)]
+
+
+class KexcPipeline(ctypes.Structure):
+    _fields_ = [("is_oracle_action", ctypes.c_int), ("nprograms", ctypes.c_uint32), ("programs", ctypes.POINTER(KexcIlProgram))]
+
+
+def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bits=8, copt=3, cc="cc", word_alignment=True,
+                  oracle_action=False, info=None):
+    """compileProgram's seam (include/kexc_api.h::kexc_emit_pipeline): `programs` is a list of dicts of numpy arrays
+    (keys = the fields of kexc_il_program).  Returns the exit code; raises CompileError with the message on failure."""
+    import numpy as np
+    lib = load_compiler()
+    keep, structs = [], (KexcIlProgram * len(programs))()
+    kinds = {"class_of": np.uint8, "delta": np.uint16, "action": np.uint32, "final_action": np.uint32, "action_off": np.uint32, "ops": np.uint32,
+             "const_off": np.uint32, "const_pool": np.uint8, "back_row": np.uint32, "nleaves": np.uint8, "final_leaf": np.uint8,
+             "back": np.uint32, "pconst_off": np.uint32, "pconst_pool": np.uint8, "init_const": np.uint32}
+    for st, P in zip(structs, programs):
+        for k in ("nstates", "nclasses", "init_state", "nregs", "nactions", "nconsts", "maxleaves", "nback", "npconsts"):
+            setattr(st, k, int(P[k]))
+        for k, dt in kinds.items():
+            a = np.ascontiguousarray(np.asarray(P[k], dtype=dt).ravel())
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)
+            keep.append(a)
+            setattr(st, k, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8 if dt == np.uint8 else ctypes.c_uint16 if dt == np.uint16 else ctypes.c_uint32)))
+    pl = KexcPipeline(1 if oracle_action else 0, len(programs), structs)
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_void_p)
+    cb = CB((lambda line, ctx: info(line.decode())) if info else (lambda line, ctx: None))
+    lib.kexc_emit_pipeline.argtypes = [ctypes.c_int, ctypes.c_int, CB, ctypes.c_void_p, ctypes.POINTER(KexcPipeline), ctypes.c_char_p,
+                                       ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    enc = lambda x: None if x is None else str(x).encode()
+    rc = lib.kexc_emit_pipeline(buffer_unit_bits, copt, cb, None, ctypes.byref(pl), enc(env_info), enc(cc), enc(out), enc(srcout), 1 if word_alignment else 0)
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    return rc
+
+
 def program_path(name):
     p = os.path.join(PROGRAM_DIR, name if name.endswith(".kex") else name + ".kex")
     if not os.path.exists(p):

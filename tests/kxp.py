@@ -41,8 +41,8 @@ def parse(blob):
         s.delta = take(np.uint16, sc).reshape(s.nstates, s.nclasses)
         s.act = take(np.uint32, sc)
         s.final_act = take(np.uint32, s.nstates)
-        take(np.uint32, nact + 1); take(np.uint32, nops * 2)
-        take(np.uint32, nconsts + 1); take(np.uint8, cpl)
+        s.act_off = take(np.uint32, nact + 1); s.ops = take(np.uint32, nops * 2)
+        s.const_off = take(np.uint32, nconsts + 1); s.cpool = bytes(take(np.uint8, cpl))
         s.pback = take(np.uint32, sc).reshape(s.nstates, s.nclasses)
         s.nleaves = take(np.uint8, s.nstates)
         s.fin_leaf = take(np.uint8, s.nstates)

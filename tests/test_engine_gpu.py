@@ -384,3 +384,27 @@ def test_phase_option_runs_one_stage_of_a_pipeline(tmp_path):
     assert p2 == whole
     r = subprocess.run([str(exe), "--phase", "3"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and b"Invalid phase: 3 given" in r.stderr
+
+
+def test_pipeline_handed_over_as_tables_runs_on_the_engine(tmp_path):
+    """The compile-side seam (kexc_emit_pipeline = compileProgram): a hand-marshalled flip_ab program and a workload
+    program taken apart into tables both run on the GPU like their source-compiled twins."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kxp
+    from test_pipeline_seam import flip_ab_program, marshal
+    from kleenexlang_amd import emit_pipeline
+    out = tmp_path / "flip.kxp"
+    emit_pipeline([flip_ab_program()], srcout=out)
+    p = Program(out.read_bytes())
+    data = b"abba\nbb\n" * 5000
+    assert p.run_host(data) == b"baab\naa\n" * 5000
+    with pytest.raises(MatchError) as e:
+        p.run_host(b"ab" * 40 + b"x")
+    assert e.value.pos == 80
+    p.close()
+    emit_pipeline([marshal(s) for s in kxp.parse(blob_of("csv2json"))], srcout=out)
+    data = workloads.generate("csv", 300000, 8)
+    p = Program(out.read_bytes())
+    assert p.run_host(data) == oracle.run(blob_of("csv2json"), data)
+    p.close()

@@ -1,0 +1,95 @@
+"""CPU: the compile-side seam that takes a `Pipeline` (include/kexc_api.h::kexc_emit_pipeline = compileProgram,
+src/KMC/Program/Backends/C.hs:529-540): a front end with its own SSTs hands over tables, not source text."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from conftest import blob_of
+
+from kleenexlang_amd import CompileError, emit_pipeline, workloads
+from oracle import oracle
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kxp  # noqa: E402
+
+
+def flip_ab_program():
+    """`main := ("b" ~/a/ | "a" ~/b/ | /\\n/)*` marshalled BY HAND the way a Haskell caller would (SURVEY App. B shows the
+    reference's one-state program): one block, output register only; classes a / b / newline / anything else."""
+    cls = np.full(256, 3, dtype=np.uint8)
+    cls[ord("a")], cls[ord("b")], cls[ord("\n")] = 0, 1, 2
+    return dict(
+        nstates=1, nclasses=4, init_state=0, nregs=1, class_of=cls,
+        delta=[0, 0, 0, 0xFFFF], action=[0, 1, 2, 0], final_action=[3],
+        # actions: 0 = outputarray("b"); 1 = outputarray("a"); 2 = outputconst(next[0]); 3 = nothing (accept)
+        nactions=4, action_off=[0, 1, 2, 3, 3], ops=[(1 << 24) | 0, 0, (1 << 24) | 0, 1, (2 << 24) | 0, 0],
+        nconsts=2, const_off=[0, 1, 2], const_pool=list(b"ba"),
+        # path tree: a single path; every step extends leaf 0
+        maxleaves=1, nback=3, back_row=[0, 1, 2, 0], nleaves=[1], final_leaf=[0],
+        back=[0 | (0 << 8) | (1 << 9), 0 | (0 << 8) | (2 << 9), 0 | (1 << 8) | (0 << 9)],
+        npconsts=3, pconst_off=[0, 0, 1, 2], pconst_pool=list(b"ba"), init_const=[0])
+
+
+def test_hand_built_flip_ab_pipeline_runs_like_the_reference(tmp_path):
+    src = tmp_path / "flip.kxp"
+    lines = []
+    assert emit_pipeline([flip_ab_program()], env_info="hand-made flip_ab", srcout=src, info=lines.append) == 0
+    assert lines and "KXP table blob" in lines[0]
+    blob = src.read_bytes()
+    assert oracle.run(blob, b"abba\nbb\n") == b"baab\naa\n"                  # observed with the reference runtime
+    assert oracle.run(blob, b"abba\nbb\n", path_form=True) == b"baab\naa\n"
+    with pytest.raises(oracle.OracleMatchError) as e:
+        oracle.run(blob, b"abxa\n")
+    assert e.value.pos == 2                                                   # "Match error at input symbol 2!"
+    assert oracle.run(blob, b"") == b""
+
+
+def test_out_writes_a_runnable_binary_and_info_text(tmp_path):
+    exe = tmp_path / "flip"
+    assert emit_pipeline([flip_ab_program()], env_info="Options:\\nhand-made", out=exe) == 0
+    r = subprocess.run([str(exe), "-i"], stdout=subprocess.PIPE)
+    assert r.returncode == 2 and b"hand-made" in r.stdout                     # crt.c:384-386: -i prints the info, exit 2
+
+
+def marshal(stage):
+    """A parsed KXP stage (tests/kxp.py) as the dict emit_pipeline takes — what a Haskell front end would marshal."""
+    return dict(nstates=stage.nstates, nclasses=stage.nclasses, init_state=stage.q0, nregs=stage.nregs, class_of=stage.cls,
+                delta=stage.delta, action=stage.act, final_action=stage.final_act,
+                nactions=len(stage.act_off) - 1, action_off=stage.act_off, ops=stage.ops,
+                nconsts=len(stage.const_off) - 1, const_off=stage.const_off, const_pool=np.frombuffer(stage.cpool, dtype=np.uint8),
+                maxleaves=stage.maxleaves, nback=stage.back.shape[0], back_row=stage.pback, nleaves=stage.nleaves, final_leaf=stage.fin_leaf,
+                back=stage.back, npconsts=len(stage.pconst_off) - 1, pconst_off=stage.pconst_off,
+                pconst_pool=np.frombuffer(stage.pool, dtype=np.uint8), init_const=stage.init_const)
+
+
+@pytest.mark.parametrize("prog", ["apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep", "add_commas"])
+def test_tables_in_equal_source_in(prog, tmp_path):
+    """Every workload program, taken apart into tables and handed to kexc_emit_pipeline, gives byte for byte the stages
+    that kexc_compile builds from the source (the synchronising automaton is rebuilt from delta), and the same output."""
+    blob = blob_of(prog)
+    stages = kxp.parse(blob)
+    out = tmp_path / "p.kxp"
+    emit_pipeline([marshal(s) for s in stages], env_info="", srcout=out)
+    again = out.read_bytes()
+    il = struct.unpack_from("<I", blob, 16)[0]
+    assert again[20:] == blob[20 + ((il + 3) & ~3):]                           # identical stage sections (info text aside)
+    data = workloads.generate(workloads.PROGRAM_INPUT[prog], 20000, 3) if prog in workloads.PROGRAM_INPUT else workloads.digits(5000)
+    assert oracle.run(again, data) == oracle.run(blob, data)
+
+
+def test_multi_stage_and_argument_errors(tmp_path):
+    src = 'start: a >> b\na := (/x/ "1" | /y/)*\nb := (~/1/ "one" | /./)*\n'
+    stages = kxp.parse(blob_of(src))
+    out = tmp_path / "two.kxp"
+    emit_pipeline([marshal(s) for s in stages], srcout=out)
+    assert oracle.run(out.read_bytes(), b"xyx") == oracle.run(blob_of(src), b"xyx") == b"xoneyxone"
+    with pytest.raises(CompileError, match="8 bits"):
+        emit_pipeline([flip_ab_program()], srcout=out, buffer_unit_bits=16)     # --wordsize 16 is not built
+    with pytest.raises(CompileError, match="oracle/action"):
+        emit_pipeline([flip_ab_program(), flip_ab_program()], srcout=out, oracle_action=True)
+    bad = flip_ab_program(); bad["delta"] = [0, 7, 0, 0xFFFF]
+    with pytest.raises(CompileError, match="out of range"):
+        emit_pipeline([bad], srcout=out)

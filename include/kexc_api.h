@@ -54,6 +54,9 @@ typedef struct kexc_il_program {
   const uint32_t* back;           /* [nback*maxleaves] */
   uint32_t npconsts; const uint32_t* pconst_off; const uint8_t* pconst_pool;
   const uint32_t* init_const;     /* [maxleaves] */
+  /* register actions: non-zero = the program's output is a token stream (escape byte 0xFF: FF FF = byte FF, FF 00 Push,
+   * FF 01 r Pop r, FF 02 r Write r; kxp_format.h) to be replayed by the action interpreter with `action_regs` registers */
+  uint32_t has_actions, action_regs;
 } kexc_il_program;
 
 /* `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per

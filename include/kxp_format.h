@@ -19,7 +19,7 @@
  *   u32   version (=1), nstages, info_len ; u8 info[info_len]
  *   per stage:
  *     u32 'KXST', nstates, nclasses, q0, nregs, nactions, nops, nconsts, constpool_len,
- *         maxleaves, nback, npconsts, pconstpool_len, nsync, sync_complete, reserved
+ *         maxleaves, nback, npconsts, pconstpool_len, nsync, sync_complete, actions
  *     u8  cls[256]
  *     u16 delta[nstates*nclasses]            0xFFFF = no transition (FailI)
  *     u32 act[nstates*nclasses]              action id
@@ -33,6 +33,13 @@
  *     u32 pconst_off[npconsts+1] ; u8 pconstpool[]
  *     u32 init_const[maxleaves]              pconst per leaf of q0's closure
  *     u32 sync_next[nsync*nclasses] ; u32 sync_state[nsync]
+ *
+ * Register actions (`r@t`, `!r`, `[r <- …]`, `[r += …]`; Kleenex/Actions.hs:28-38).  `actions` = 0: the stage's output is
+ * final.  `actions` = 1 | nregs << 8: the stage's output is a TOKEN STREAM that an action interpreter replays on a stack of
+ * buffers and nregs registers before it leaves the stage (action post-pass) — escape byte 0xFF:
+ *     FF FF   the byte 0xFF            FF 00   Push: a new empty buffer on the stack
+ *     FF 01 r Pop r: register r := top buffer, popped            FF 02 r Write r: top buffer ++= register r; r := empty
+ *     any other byte: appended to the top buffer.   The stage's output is the bottom buffer.
  */
 #ifndef KXP_FORMAT_H
 #define KXP_FORMAT_H
@@ -56,5 +63,11 @@
 #define KXP_SYNC_MULTI 0xFFFFFFFFu   /* several states still possible */
 #define KXP_SYNC_EMPTY 0xFFFFFFFEu   /* every start state has failed */
 #define KXP_SYNC_UNKNOWN 0xFFFFFFFDu /* subset construction was capped here */
+
+/* action tokens (second byte after KXP_ESC) */
+#define KXP_ESC 0xFFu
+#define KXP_TOK_PUSH 0x00u
+#define KXP_TOK_POP 0x01u
+#define KXP_TOK_WRITE 0x02u
 
 #endif

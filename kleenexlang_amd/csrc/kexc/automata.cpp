@@ -21,7 +21,26 @@
 namespace kexc {
 
 // ======================================================================= FST
-FST constructTransducer(const RProg& rp, int start) {
+// Register actions.  The reference runs a program with actions as two machines per stage: an oracle that codes the path
+// taken and an action machine that replays it on a stack of buffers (ActionSST.hs:47-104, Actions.hs:28-38).  Here the
+// transducer itself stays one machine whose OUTPUT carries the actions in band, and the stage is followed by an action
+// interpreter (include/kxp_format.h, "action post-pass").  Token code, escape byte 0xFF:
+//   FF FF      the byte 0xFF (from a constant or copied from the input)
+//   FF 00      Push            FF 01 r   Pop r            FF 02 r   Write r
+bool stageHasActions(const RProg& rp, int start) {
+  std::set<int> seen; std::vector<int> todo{start};
+  while (!todo.empty()) {
+    int i = todo.back(); todo.pop_back();
+    if (!seen.insert(i).second) continue;
+    auto it = rp.decls.find(i);
+    if (it == rp.decls.end()) continue;
+    if (it->second.kind == RTerm::RConst && it->second.c.kind != 0) return true;
+    for (int j : it->second.ids) todo.push_back(j);
+  }
+  return false;
+}
+
+FST constructTransducer(const RProg& rp, int start, bool tokens) {
   using Stack = std::vector<int>;
   auto getDecl = [&](int i) -> const RTerm& {
     auto it = rp.decls.find(i);
@@ -54,10 +73,16 @@ FST constructTransducer(const RProg& rp, int start) {
     const RTerm& d = getDecl(q[0]);
     switch (d.kind) {
       case RTerm::RConst: {
-        if (d.c.kind != 0)  // Commands.hs:165-168
-          throw CompileError("Transducer contains action symbols - direct SST generation not supported");
+        std::string out;
+        if (d.c.kind != 0) {
+          if (!tokens)  // Commands.hs:165-168
+            throw CompileError("Transducer contains action symbols - direct SST generation not supported");
+          if (d.c.kind != 1 && (d.c.arg < 0 || d.c.arg > 250)) throw CompileError("too many registers (at most 251)");
+          out = d.c.kind == 1 ? std::string("\xFF\x00", 2) : std::string(d.c.kind == 2 ? "\xFF\x01" : "\xFF\x02", 2) + char(d.c.arg);
+        } else if (tokens && (d.c.arg & 0xFF) == 0xFF) out = "\xFF\xFF";
+        else out = std::string(1, char(d.c.arg));
         Stack t = follow(rest); ws.insert(t);
-        edges.push_back({q, false, {}, false, std::string(1, char(d.c.arg)), t}); break;
+        edges.push_back({q, false, {}, false, out, t}); break;
       }
       case RTerm::RRead: {
         Stack t = follow(rest); ws.insert(t);
@@ -89,6 +114,23 @@ FST constructTransducer(const RProg& rp, int start) {
   for (auto& e : edges) {
     if (e.is_sym) f.sym[id[e.from]].push_back({e.pred, e.copy, id[e.to]});
     else f.eps[id[e.from]].push_back({e.out, id[e.to]});
+  }
+  if (tokens) {
+    // a copied input byte 0xFF must leave the transducer escaped: a copying symbol edge whose predicate contains 0xFF is
+    // split into (predicate without 0xFF, copy) and (0xFF, no copy) followed by the constant FF FF
+    const int n0 = f.nstates;
+    for (int q = 0; q < n0; ++q) {
+      if (f.sym[q].size() != 1 || !f.sym[q][0].copy || !f.sym[q][0].pred.has(0xFF)) continue;
+      const FST::Sym e = f.sym[q][0];
+      f.sym[q].clear();
+      auto fresh = [&]() { f.eps.emplace_back(); f.sym.emplace_back(); f.is_final.push_back(0); return f.nstates++; };
+      ByteSet rest = e.pred.minus(ByteSet::single(0xFF));
+      if (!rest.empty()) { int a = fresh(); f.sym[a].push_back({rest, true, e.to}); f.eps[q].push_back({"", a}); }
+      int b = fresh(), c = fresh();
+      f.sym[b].push_back({ByteSet::single(0xFF), false, c});
+      f.eps[c].push_back({std::string("\xFF\xFF", 2), e.to});
+      f.eps[q].push_back({"", b});
+    }
   }
   return f;
 }

@@ -20,14 +20,16 @@ Compiled compileSource(const std::string& src, const std::string& srcname, const
   Prog ast = parseKleenex(src, srcname);
   RProg rp = desugar(ast);
   for (int start : rp.pipeline) {
-    FST f = constructTransducer(rp, start);
+    const bool acts = stageHasActions(rp, start);   // register actions: in-band tokens + the action post-pass
+    FST f = constructTransducer(rp, start, acts && o.act);   // (--act=false = compileDirect: refuses them, Commands.hs:165-168)
     SST sst = determinize(f);                 // --la=false semantics (singletonMode)
     optimizeSST(sst, o.opt);
     out.sst_states.push_back((int)sst.states.size());
     out.stages.push_back(lower(sst, sst));
+    if (acts) out.stages.back().act_regs = (int)rp.regnames.size();
   }
   std::ostringstream info;                    // Commands.hs:191-199
-  info << "Options:\\n--opt " << o.opt << " --la=false --act=false (direct mode)\\n\\nSource file: " << srcname
+  info << "Options:\\n--opt " << o.opt << " --la=false --act=" << (o.act ? "true" : "false") << "\\n\\nSource file: " << srcname
        << "\\nSST states:  ";
   for (size_t i = 0; i < out.sst_states.size(); ++i) info << (i ? ", " : "") << out.sst_states[i];
   out.info = info.str();
@@ -102,8 +104,9 @@ int kexc_dump_fst(const char* source, size_t source_len, const char* source_name
     std::ostringstream o;
     o << "[";
     for (size_t si = 0; si < rp.pipeline.size(); ++si) {
-      kexc::FST f = kexc::constructTransducer(rp, rp.pipeline[si]);
-      o << (si ? "," : "") << "{\"nstates\":" << f.nstates << ",\"init\":" << f.init << ",\"final\":[";
+      const bool toks = kexc::stageHasActions(rp, rp.pipeline[si]);
+      kexc::FST f = kexc::constructTransducer(rp, rp.pipeline[si], toks);
+      o << (si ? "," : "") << "{\"tokens\":" << (toks ? "true" : "false") << ",\"nstates\":" << f.nstates << ",\"init\":" << f.init << ",\"final\":[";
       bool first = true;
       for (int q = 0; q < f.nstates; ++q) if (f.is_final[q]) { o << (first ? "" : ",") << q; first = false; }
       o << "],\"eps\":[";
@@ -200,6 +203,8 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= P.npconsts)) bad("backward entry out of range");
       t.init_const.assign(P.init_const, P.init_const + P.maxleaves);
       for (uint32_t v : t.init_const) if (v >= P.npconsts) bad("initial constant out of range");
+      if (P.action_regs > 250) bad("too many action registers");
+      t.act_regs = P.has_actions ? (int)P.action_regs : -1;
       buildSync(t);
       stages.push_back(std::move(t));
     }

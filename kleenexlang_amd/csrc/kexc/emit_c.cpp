@@ -43,6 +43,7 @@ std::string predExpr(const ByteSet& p) {
 }  // namespace
 
 std::string emitC(const std::vector<StageTables>& stages, const std::string& info) {
+  for (auto& t : stages) if (t.act_regs >= 0) throw CompileError("--backend=c prints direct-mode programs only (this one has register actions)");
   std::ostringstream o;
   o << "\n#define NUM_PHASES " << stages.size() << "\n#define BUFFER_UNIT_T uint8_t\n#include \"crt.c\"\n";
   o << "/* no tables */\n";

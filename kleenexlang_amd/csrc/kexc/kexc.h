@@ -108,7 +108,9 @@ struct FST {  // SymbolicFST.hs:49-55; states are ints after enumerateStates
   std::vector<std::vector<Eps>> eps;
   std::vector<std::vector<Sym>> sym;
 };
-FST constructTransducer(const RProg& rp, int start);  // fails on register actions (direct mode)
+bool stageHasActions(const RProg& rp, int start);
+// tokens = false: direct mode, fails on register actions; true: actions and the byte 0xFF leave as escape tokens (automata.cpp)
+FST constructTransducer(const RProg& rp, int start, bool tokens = false);
 
 // ---------------------------------------------------------------- the SST
 struct Atom {  // SymbolicSST.hs:52-56
@@ -160,6 +162,7 @@ struct StageTables {
   std::vector<uint32_t> sync_next;    // [nsync*nclasses]
   std::vector<uint32_t> sync_state;   // [nsync]: state id if singleton, 0xFFFFFFFE empty, 0xFFFFFFFF otherwise
   bool sync_complete = true;          // false if the subset construction hit its cap
+  int act_regs = -1;                  // ≥ 0: the stage's output is a token stream for the action interpreter with that many registers
 };
 StageTables lower(const SST& s, const SST& path_src);
 void buildSync(StageTables& t);            // fills sync_next / sync_state from delta

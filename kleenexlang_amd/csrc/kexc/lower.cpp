@@ -235,7 +235,7 @@ std::vector<uint8_t> writeBlob(const std::vector<StageTables>& stages, const std
     w.u32(KXP_STAGE_MAGIC); w.u32(t.nstates); w.u32(t.nclasses); w.u32(t.q0); w.u32(t.nregs);
     w.u32((uint32_t)t.actions.size()); w.u32((uint32_t)nops); w.u32((uint32_t)t.consts.size()); w.u32((uint32_t)cpl);
     w.u32(t.maxleaves); w.u32(nback); w.u32((uint32_t)t.pconsts.size()); w.u32((uint32_t)pcpl);
-    w.u32(nsync); w.u32(t.sync_complete ? 1 : 0); w.u32(0);
+    w.u32(nsync); w.u32(t.sync_complete ? 1 : 0); w.u32(t.act_regs >= 0 ? 1u | ((uint32_t)t.act_regs << 8) : 0u);
     w.raw(t.cls, 256);
     for (auto v : t.delta) w.u16(v);
     w.pad();

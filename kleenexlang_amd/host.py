@@ -203,7 +203,8 @@ class KexcIlProgram(ctypes.Structure):
                 ("nconsts", ctypes.c_uint32), ("const_off", _u32p), ("const_pool", _u8p),
                 ("maxleaves", ctypes.c_uint32), ("nback", ctypes.c_uint32), ("back_row", _u32p),
                 ("nleaves", _u8p), ("final_leaf", _u8p), ("back", _u32p),
-                ("npconsts", ctypes.c_uint32), ("pconst_off", _u32p), ("pconst_pool", _u8p), ("init_const", _u32p)]
+                ("npconsts", ctypes.c_uint32), ("pconst_off", _u32p), ("pconst_pool", _u8p), ("init_const", _u32p),
+                ("has_actions", ctypes.c_uint32), ("action_regs", ctypes.c_uint32)]
 
 
 class KexcPipeline(ctypes.Structure):
@@ -223,6 +224,7 @@ def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bi
     for st, P in zip(structs, programs):
         for k in ("nstates", "nclasses", "init_state", "nregs", "nactions", "nconsts", "maxleaves", "nback", "npconsts"):
             setattr(st, k, int(P[k]))
+        st.has_actions, st.action_regs = int(P.get("has_actions", 0)), int(P.get("action_regs", 0))
         for k, dt in kinds.items():
             a = np.ascontiguousarray(np.asarray(P[k], dtype=dt).ravel())
             if a.size == 0:

@@ -67,4 +67,36 @@ def run(fsts, data):
         cur = run_stage(f, cur)
         if cur is None:
             return None
+        if f.get("tokens"):          # the stage has register actions: its output is a token stream
+            cur = replay_actions(cur)
     return cur
+
+
+def replay_actions(tokens):
+    """The action post-pass on a token stream (include/kxp_format.h), stated directly from the reference's semantics
+    (src/KMC/Kleenex/Actions.hs:28-38): state = (register store, stack of buffers), start (empty, [empty]);
+    inj w appends to the top buffer; psh pushes an empty buffer; pop r stores the top buffer in r and pops it;
+    wr r appends register r to the top buffer and clears r.  The result is the bottom buffer."""
+    store, stack = {}, [bytearray()]
+    i, n = 0, len(tokens)
+    while i < n:
+        b = tokens[i]
+        i += 1
+        if b != 0xFF:
+            stack[-1].append(b)
+            continue
+        k = tokens[i]
+        i += 1
+        if k == 0xFF:
+            stack[-1].append(0xFF)
+        elif k == 0:
+            stack.append(bytearray())
+        else:
+            r = tokens[i]
+            i += 1
+            if k == 1:
+                store[r] = stack.pop()
+            else:
+                stack[-1] += store.get(r, b"")
+                store[r] = bytearray()
+    return bytes(stack[0])

@@ -33,7 +33,7 @@
 
 typedef struct {
   uint32_t nstates, nclasses, q0, nregs, nactions, nops, nconsts, constpool_len;
-  uint32_t maxleaves, nback, npconsts, pconstpool_len, nsync, sync_complete;
+  uint32_t maxleaves, nback, npconsts, pconstpool_len, nsync, sync_complete, actions;
   const uint8_t* cls;
   const uint16_t* delta;
   const uint32_t *act, *final_act, *act_off, *ops, *const_off;
@@ -65,7 +65,7 @@ static int parse_blob(const uint8_t* b, size_t len, prog_t* p) {
     if (h[0] != KXP_STAGE_MAGIC) return -1;
     t->nstates = h[1]; t->nclasses = h[2]; t->q0 = h[3]; t->nregs = h[4]; t->nactions = h[5]; t->nops = h[6];
     t->nconsts = h[7]; t->constpool_len = h[8]; t->maxleaves = h[9]; t->nback = h[10]; t->npconsts = h[11];
-    t->pconstpool_len = h[12]; t->nsync = h[13]; t->sync_complete = h[14];
+    t->pconstpool_len = h[12]; t->nsync = h[13]; t->sync_complete = h[14]; t->actions = h[15];
     size_t sc = (size_t)t->nstates * t->nclasses;
     t->cls = c; c += 256;
     t->delta = (const uint16_t*)c; c += pad4(sc * 2);
@@ -179,6 +179,41 @@ done:
   return rc;
 }
 
+/* The action post-pass of a stage (kxp_format.h): replays the token stream on a stack of buffers and a register bank —
+ * the semantics of src/KMC/Kleenex/Actions.hs:28-38 (inj / psh / pop / wr, starting from ([], [mempty])); the result is
+ * the bottom buffer.  What the reference's action SST (ActionSST.hs:85-104) computes with stack-indexed registers. */
+static void run_actions(uint32_t nregs, const uint8_t* in, size_t n, buf_t* out) {
+  buf_t* regs = (buf_t*)calloc(nregs ? nregs : 1, sizeof(buf_t));
+  for (uint32_t r = 0; r < nregs; ++r) buf_init(&regs[r]);
+  size_t cap = 16, depth = 1;
+  buf_t* stack = (buf_t*)calloc(cap, sizeof(buf_t));
+  buf_init(&stack[0]);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t b = in[i];
+    if (b != KXP_ESC) { buf_append(&stack[depth - 1], &b, 1); continue; }       /* inj */
+    const uint8_t k = i + 1 < n ? in[++i] : KXP_ESC;
+    if (k == KXP_ESC) { buf_append(&stack[depth - 1], &k, 1); continue; }       /* inj 0xFF */
+    if (k == KXP_TOK_PUSH) {                                                     /* psh */
+      if (depth == cap) { cap *= 2; stack = (buf_t*)realloc(stack, cap * sizeof(buf_t)); }
+      buf_init(&stack[depth++]);
+      continue;
+    }
+    const uint8_t r = i + 1 < n ? in[++i] : 0;
+    if (r >= nregs) continue;
+    if (k == KXP_TOK_POP && depth > 1) {                                         /* pop r */
+      free(regs[r].data);
+      regs[r] = stack[--depth];
+    } else if (k == KXP_TOK_WRITE) {                                             /* wr r */
+      buf_append(&stack[depth - 1], regs[r].data, regs[r].len);
+      regs[r].len = 0;
+    }
+  }
+  buf_append(out, stack[0].data, stack[0].len);
+  for (size_t d = 0; d < depth; ++d) free(stack[d].data);
+  for (uint32_t r = 0; r < nregs; ++r) free(regs[r].data);
+  free(stack); free(regs);
+}
+
 static int run_all(const uint8_t* blob, size_t blob_len, const uint8_t* in, size_t n, uint8_t** outp, size_t* out_len,
                    uint64_t* fail_pos, uint32_t* fail_stage, int path) {
   prog_t p;
@@ -193,6 +228,12 @@ static int run_all(const uint8_t* blob, size_t blob_len, const uint8_t* in, size
     free(owned);
     owned = out.data; cur = owned; curn = out.len;
     if (rc) { *fail_pos = fp; *fail_stage = s; break; }
+    if (p.st[s].actions & 1u) {
+      buf_t fin; buf_init(&fin);
+      run_actions(p.st[s].actions >> 8, cur, curn, &fin);
+      free(owned);
+      owned = fin.data; cur = owned; curn = fin.len;
+    }
   }
   free(p.st);
   *outp = owned; *out_len = curn;

@@ -32,10 +32,10 @@ def test_reference_exact_tests(vectors, opt, path_form):
             assert got == out.encode("utf-8"), (t["name"], inp, got)
 
 
-def test_direct_mode_rejects_register_actions(vectors):
+def test_programs_direct_mode_rejects_now_run_with_the_action_post_pass(vectors):
+    """What `--act=false` refuses (Commands.hs:165-168) compiles by default: tests/test_register_actions.py holds the vectors."""
     for t in vectors["direct_mode_rejects"]:
-        with pytest.raises(CompileError, match="action symbols"):
-            blob_of(t["program"])
+        assert oracle.run(blob_of(t["program"]), "c\n".encode()) == "ø".encode()
 
 
 def test_state_counts_match_literal_restatement(vectors):

@@ -44,16 +44,12 @@ def test_every_action_free_bench_program_compiles_and_fits_the_engine_limits():
     for name in _programs():
         if name in HUGE:
             continue
-        if name in NEEDS_ACTIONS:
-            with pytest.raises(CompileError, match="action symbols"):   # the reference's own direct-mode error (Commands.hs:165-168)
-                host.compile_source(_source(name), opt=0)
-            continue
-        info = oracle.info(host.compile_source(_source(name), opt=3))
+        info = oracle.info(host.compile_source(_source(name), opt=0 if name in NEEDS_ACTIONS else 3))   # (actions: tokens + post-pass)
         if 256 + (info["nstates"] + 1) * info["nclasses"] * 4 <= 0xFFF0:
             fits += 1
         else:
             too_big += 1
-    assert fits >= 38 and too_big <= 1, (fits, too_big)   # make_danish (1039 states x 34 classes) is the one outside
+    assert fits >= 45 and too_big <= 6, (fits, too_big)   # make_danish (1039 states x 34 classes) and a few action programs are outside
 
 
 def test_three_routes_agree_on_the_reference_sample_data():

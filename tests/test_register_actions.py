@@ -1,0 +1,98 @@
+"""CPU: register actions (`r@t`, `!r`, `[r <- …]`, `[r += …]`).  The transducer carries the actions in
+band as escape tokens and the stage ends with the action post-pass (include/kxp_format.h); the reference replays them with
+an action SST on a stack of registers (ActionSST.hs:47-104, Actions.hs:28-38) — same bytes out."""
+import json
+import os
+import random
+
+import pytest
+from conftest import GOLDEN, blob_of, line_expected, line_input, same_modulo_trailing_newlines
+
+from kleenexlang_amd import host
+from oracle import fst_sim, oracle
+
+
+@pytest.fixture(scope="module")
+def action_vectors():
+    with open(os.path.join(GOLDEN, "action_vectors.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+@pytest.mark.parametrize("path_form", [False, True])
+def test_reference_action_vectors(action_vectors, opt, path_form):
+    """actionbug (test_compiled) and makeDanish (test_simulated): the reference's own `// IN:` / `// OUT:` lines."""
+    for t in action_vectors["line_tests"]:
+        if t["name"] == "makeDanish" and opt == 0:
+            continue   # (a minute of compile time per optimisation level; level 3 is the reference default)
+        got = oracle.run(blob_of(t["program"], opt), line_input(t["in"]), path_form=path_form)
+        assert same_modulo_trailing_newlines(got, line_expected(t["out"])), (t["name"], got)
+
+
+PROGRAMS = {
+    # redirect + write (the desugaring of Desugaring.hs:163-169: r@t = Push t Pop r; !r = Write r)
+    "swap_fields": 'main := (a@/[a-z]*/ ~/,/ b@/[0-9]*/ !b "," !a /\\n/)*\n',
+    # [r <- …] and [r += …]: registers built up over a loop and written once
+    "accumulate": 'main := [acc <- ""] (word)* "=" !acc\nword := w@/[a-z]+/ [acc += w "+"] ~/ /\n',
+    # nested redirects, a register written twice (the second write finds it empty: wr clears it)
+    "nested": 'main := o@(i@/a*/ "<" !i ">" /b*/) !o "|" !o "|" !i\n',
+    # the byte 0xFF travels escaped through the token stream, copied and constant
+    "byte_ff": 'main := (r@/[^\\n]*/ "\\xff" !r ~/\\n/ "\\n")*\n',
+    # two stages, actions in the first only
+    "two_stage": 'start: rev >> up\nrev := (a@/[a-z]/ b@/[a-z]/ !b !a)*\nup := (~/a/ "A" | /[b-z]/)*\n',
+}
+
+
+def _replay_model(src, data):
+    """Third route: lock-step simulation of the nondeterministic transducer(s) + the action semantics stated in Python."""
+    return fst_sim.run(host.dump_fst(src), data)
+
+
+@pytest.mark.parametrize("name", sorted(PROGRAMS))
+def test_three_routes_agree_on_action_programs(name):
+    src = PROGRAMS[name]
+    rnd = random.Random(hash(name) & 0xFFFF)
+    if name == "swap_fields":
+        inputs = [b"", b"ab,12\n", b"abc,1\nx,\n,99\n"]
+    elif name == "accumulate":
+        inputs = [b"", b"ab ", b"ab cd efg "]
+    elif name == "nested":
+        inputs = [b"", b"aab", b"bbb", b"aaaa"]
+    elif name == "byte_ff":
+        inputs = [b"", b"abc\n", b"a\xffb\n\xff\xff\n", bytes(rnd.randrange(11, 256) for _ in range(300)) + b"\n"]
+    else:
+        inputs = [b"", b"ab", b"abcdxy", b"zaqa"]
+    for opt in (0, 3):
+        blob = blob_of(src, opt)
+        for data in inputs:
+            want = _replay_model(src, data)
+            for pf in (False, True):
+                if want is None:
+                    with pytest.raises(oracle.OracleMatchError):
+                        oracle.run(blob, data, path_form=pf)
+                else:
+                    assert oracle.run(blob, data, path_form=pf) == want, (name, opt, pf, data)
+    # spot checks of the meaning itself
+    if name == "swap_fields":
+        assert oracle.run(blob_of(src), b"abc,12\n") == b"12,abc\n"
+    if name == "accumulate":
+        assert oracle.run(blob_of(src), b"ab cd ") == b"=ab+cd+"
+    if name == "nested":
+        assert oracle.run(blob_of(src), b"aab") == b"<aa>b||"
+    if name == "byte_ff":
+        assert oracle.run(blob_of(src), b"a\xffb\n") == b"\xc3\xbfa\xffb\n"   # ("\xff" in a Kleenex string is U+00FF, stored UTF-8: Parser.hs:149-151)
+
+
+def test_act_false_is_the_reference_direct_mode_and_still_rejects(tmp_path):
+    """`--act=false` = compileDirect: a program with register actions is refused with the reference's message
+    (Commands.hs:165-168); the default (`--act=true`) runs it."""
+    import subprocess
+    from kleenexlang_amd import build
+    kexc = os.path.join(build.OUT, "kexc")
+    p = tmp_path / "a.kex"
+    p.write_text(PROGRAMS["swap_fields"])
+    r = subprocess.run([kexc, "compile", "--quiet", "--act=false", str(p), "--blob", str(tmp_path / "a.kxp")], stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"action symbols" in r.stderr
+    r = subprocess.run([kexc, "compile", "--quiet", str(p), "--blob", str(tmp_path / "a.kxp")], stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    assert oracle.run((tmp_path / "a.kxp").read_bytes(), b"q,7\n") == b"7,q\n"

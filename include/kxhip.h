@@ -77,6 +77,11 @@ void kx_free(kx_program* prog);
 const char* kx_last_error(void);
 int kx_set_config(kx_program* prog, const kx_config* cfg);
 uint32_t kx_num_stages(const kx_program* prog);
+/* 1: the stage uses register actions (`r@t`, `!r`, `[r <- …]`).  Its transducer output is a token stream (kxp_format.h) that
+ * kx_run_device / kx_run_host / kx_run_fd replay with the action post-pass before it leaves the stage; the replay is
+ * sequential over the whole stream (registers are unbounded), so such a stage is not run through the kx_shard_* protocol
+ * across GPUs (SURVEY §8e "pathological case": the boundary tuple would be O(N)). */
+int kx_stage_has_actions(const kx_program* prog, uint32_t stage);
 
 /* Whole program (all pipeline stages) over one device-resident input.
  * d_out may be NULL with cap 0 to query the exact output size (returned in

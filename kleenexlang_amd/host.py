@@ -118,6 +118,7 @@ def load_engine():
         lib.kx_set_config.argtypes = [vp, ctypes.POINTER(KxConfig)]
         lib.kx_num_stages.argtypes = [vp]
         lib.kx_num_stages.restype = u32
+        lib.kx_stage_has_actions.argtypes = [vp, u32]
         lib.kx_run_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(KxStats), vp]
         lib.kx_run_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz),
                                     ctypes.POINTER(KxStats)]
@@ -352,7 +353,13 @@ class Program:
         return int(n * f) + 65536
 
     # sharded protocol (one shard per rank); thin wrappers, see include/kxhip.h
+    def stage_has_actions(self, stage):
+        return bool(self._lib.kx_stage_has_actions(self._h, stage))
+
     def shard_begin(self, stage, d_in, n, is_first, is_last, stream=None):
+        if self.stage_has_actions(stage):
+            raise EngineError("stage %d uses register actions: their replay is sequential over the whole stream, "
+                              "run the program unsharded (kx_run_device / kx_run_fd)" % stage)
         return Shard(self, stage, d_in, n, is_first, is_last, stream)
 
 

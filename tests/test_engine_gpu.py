@@ -408,3 +408,46 @@ def test_pipeline_handed_over_as_tables_runs_on_the_engine(tmp_path):
     p = Program(out.read_bytes())
     assert p.run_host(data) == oracle.run(blob_of("csv2json"), data)
     p.close()
+
+
+def test_register_actions_on_the_engine(tmp_path):
+    """programs with register actions run on the GPU — transducer (tokens in band) + action post-pass —
+    and give the reference's vectors (actionbug, makeDanish), the oracle's output on larger inputs (arena growth: frames
+    and registers of megabytes), and the same through the produced binary in small windows (tokens cut by window ends,
+    frames and registers carried from window to window)."""
+    import json
+    import subprocess
+    from kleenexlang_amd import build
+    from test_register_actions import PROGRAMS
+    av = json.load(open(os.path.join(GOLDEN, "action_vectors.json"), encoding="utf-8"))
+    for t in av["line_tests"]:
+        if t["name"] == "makeDanish":
+            continue   # 658 states x 47 classes: beyond the engine's 64 KiB table image (DESIGN.md limits); the oracle runs it
+        p = Program(blob_of(t["program"], 0))
+        assert p.stage_has_actions(0)
+        got = p.run_host(line_input(t["in"]))
+        assert same_modulo_trailing_newlines(got, line_expected(t["out"])), t["name"]
+        p.close()
+    rnd = random.Random(3)
+    words = lambda k: b"".join(bytes(rnd.choice(b"abcxyz") for _ in range(rnd.randint(1, 9))) + b"," + str(rnd.randint(0, 10 ** rnd.randint(1, 8))).encode() + b"\n" for _ in range(k))
+    cases = [("swap_fields", words(60000)), ("accumulate", b"".join(bytes(rnd.choice(b"abc") for _ in range(rnd.randint(1, 6))) + b" " for _ in range(6000))),   # (quadratic: acc is copied per word)
+             ("nested", b"a" * 3000000 + b"b" * 70000), ("byte_ff", bytes(rnd.choice(b"ab\xff\xfe\n") for _ in range(500000)) + b"\n"),
+             ("two_stage", bytes(rnd.choice(b"abcz") for _ in range(400000)))]
+    kexc = os.path.join(build.OUT, "kexc")
+    for name, data in cases:
+        src = PROGRAMS[name]
+        want = oracle.run(blob_of(src), data)
+        p = Program(blob_of(src), segment_bytes=4096)
+        assert p.run_host(data) == want, name
+        p.close()
+        path = tmp_path / (name + ".kex"); path.write_text(src)
+        exe = tmp_path / name
+        assert subprocess.run([kexc, "compile", "--quiet", str(path), "--out", str(exe)]).returncode == 0
+        for window in (4096, 50000, 1 << 30):
+            r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KX_WINDOW_BYTES=str(window)))
+            assert r.returncode == 0 and r.stdout == want, (name, window, r.stderr[-300:])
+    # sharding such a stage is refused
+    p = Program(blob_of(PROGRAMS["swap_fields"]))
+    with pytest.raises(Exception, match="register actions"):
+        p.shard_begin(0, 0, 0, True, True)
+    p.close()

@@ -65,3 +65,17 @@ def line_expected(lines):
 def same_modulo_trailing_newlines(got, want):
     """runtest.sh compares `$(...)` captures, which drop trailing newlines."""
     return got.rstrip(b"\n") == want.rstrip(b"\n")
+
+
+def dictionary_program(nwords=100, seed=5, lo=8, hi=15):
+    """A word-for-word rewriter in the shape of the reference's bench/kleenex/src/make_danish.kex (dictionary words
+    replaced, every other word copied), generated here: ~1000 states x 28 classes, i.e. a state table of > 100 KiB —
+    beyond 16-bit LDS addressing, so the engine runs it from global memory (DevTables::big).  Returns (source, words)."""
+    import random
+    rnd = random.Random(seed)
+    words = set()
+    while len(words) < nwords:
+        words.add("".join(rnd.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rnd.randint(lo, hi))))
+    words = sorted(words)
+    alts = "\n      | ".join('~/%s/ "%s"' % (w, w[::-1].upper() + str(i)) for i, w in enumerate(words))
+    return 'main := word sep main | word | ""\nsep := /[^a-z0-9]+/\nword := %s\n      | /[a-z0-9]+/\n' % alts, words

@@ -88,3 +88,23 @@ def test_produced_binary_refuses_a_corrupt_trailer(tmp_path):
     bad.write_bytes(bytes(data)); bad.chmod(0o755)
     r = sp.run([str(bad), "-i"], stdout=sp.PIPE, stderr=sp.PIPE)
     assert r.returncode == 1 and b"corrupt" in r.stderr
+
+
+def test_big_table_programs_pass_validation():
+    """A make_danish-sized program (state table > 100 KiB) is inside the engine's limits since round 2 (image in global
+    memory, DevTables::big); one beyond 256 KiB of state table is still refused with a message."""
+    import pytest
+    from conftest import blob_of, dictionary_program
+    from kleenexlang_amd import host
+    from oracle import oracle
+    src, _ = dictionary_program()
+    blob = blob_of(src, opt=0)
+    info = oracle.info(blob)
+    assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 100 * 1024
+    host.validate_blob(blob)
+    src, _ = dictionary_program(nwords=100, lo=25, hi=32)
+    blob = blob_of(src, opt=0)
+    info = oracle.info(blob)
+    assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 256 * 1024
+    with pytest.raises(host.EngineError, match="outside engine limits"):
+        host.validate_blob(blob)

@@ -4,7 +4,7 @@ import os
 import random
 
 import pytest
-from conftest import GOLDEN, blob_of, line_expected, line_input, same_modulo_trailing_newlines
+from conftest import GOLDEN, blob_of, dictionary_program, line_expected, line_input, same_modulo_trailing_newlines
 
 from kleenexlang_amd import MatchError, Program, workloads
 from oracle import oracle
@@ -420,9 +420,7 @@ def test_register_actions_on_the_engine(tmp_path):
     from kleenexlang_amd import build
     from test_register_actions import PROGRAMS
     av = json.load(open(os.path.join(GOLDEN, "action_vectors.json"), encoding="utf-8"))
-    for t in av["line_tests"]:
-        if t["name"] == "makeDanish":
-            continue   # 658 states x 47 classes: beyond the engine's 64 KiB table image (DESIGN.md limits); the oracle runs it
+    for t in av["line_tests"]:      # (makeDanish, 658 states x 47 classes, runs in the BIG table form: DESIGN.md §3)
         p = Program(blob_of(t["program"], 0))
         assert p.stage_has_actions(0)
         got = p.run_host(line_input(t["in"]))
@@ -466,11 +464,44 @@ def test_run_trace_pipeline_matches(monkeypatch):
                 assert got == want, (prog, seg, n)
     blob = blob_of("apache_log")
     data = workloads.generate("apache_log", 400000, 23)
-    bad = data[:250000] + b"\x00" + data[250000:]
-    got, want = both(blob, bad, segment_bytes=4096)
-    assert got == want and got[0] == "fail"
+    cut = data.index(b"\n", 250000) + 1
+    for bad in (data[:cut] + b"\n" + data[cut:], data[:cut + 17]):     # an empty line mid-input; input ending inside a line
+        got, want = both(blob, bad, segment_bytes=4096)
+        assert got == want and got[0] == "fail"
     # the dense kernels with the break-record output stage (k_brkref + k_emit2)
     monkeypatch.delenv("KX_SPARSE")
     monkeypatch.setenv("KX_EMIT2", "1")
     got, want = both(blob, data, segment_bytes=4096)
     assert got == want
+
+
+def test_tables_beyond_16_bit_addressing_run_from_global_memory(monkeypatch):
+    """a program whose image exceeds 64 KiB (make_danish-sized: ~1000 states x 28 classes) is not
+    refused any more — its GENERAL kernel instances read the image from global memory with scaled handles
+    (DevTables::big).  `KX_FORCE_BIG` sends the ordinary workloads down the same instances."""
+    src, words = dictionary_program()
+    blob = blob_of(src, opt=0)
+    info = oracle.info(blob)
+    assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 100 * 1024
+    rnd = random.Random(9)
+    other = ["zz", "hello", "a", "x1", "0", words[3][:-1], words[7] + "s", words[11][1:]]
+    seps = [" ", ", ", "\n", " - ", ".  ", "\t", " (", ") "]
+    text = "".join(rnd.choice(words if rnd.random() < 0.4 else other) + rnd.choice(seps) for _ in range(60000)).encode()
+    for data in [b"", b"a", text[:57], text[:4097], text[:100001], text]:
+        for seg in (64, 4096, 0):
+            got, want = both(blob, data, segment_bytes=seg)
+            assert got == want, (len(data), seg)
+    got, want = both(blob, b" " + text[:5000], segment_bytes=64)     # a leading separator is the one way to fail
+    assert got == want == ("fail", 0)
+    monkeypatch.setenv("KX_FORCE_BIG", "1")
+    for prog in ("apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"):
+        for seg in (64, 4096, 0):
+            for n, seed in [(3000, 31), (300000, 32)]:
+                data = workloads.generate(workloads.PROGRAM_INPUT[prog], n, seed)
+                got, want = both(blob_of(prog), data, segment_bytes=seg)
+                assert got == want, (prog, seg, n)
+    big = "x" * 300     # wide entries + oversize pieces on the BIG instances
+    blob = blob_of('main := (~/a/ "%s" | /b/ | ~/c/ "<%s>")*\n' % (big, "y" * 130))
+    for data in [b"a", b"abcab" * 50, b"c" * 64 + b"a" * 64, b"abc" * 3000]:
+        got, want = both(blob, data, segment_bytes=64)
+        assert got == want, len(data)

@@ -416,6 +416,61 @@ def backloop():
     return L
 
 
+PAIR_CLS2 = 16128     # k_forward's two-symbol stride: LDS address of the class table that holds class*2 (one byte per symbol)
+PAIR_TAB = 16384      # ... and of the pair table (a 16-bit DS offset field reaches it; the image's [cls4 | fwd] stays at 0)
+
+
+def run_pair():
+    """k_forward's piece for programs whose PAIR TABLE fits LDS: 32 chained lookups instead of 64.
+      pair[(q*C + c1)*C + c2] = C*C * (state after reading two symbols of classes c1, c2 in state q)     (u16)
+    so the chain value e IS the index of the next state's row:  e' = pair[e + c1*C + c2].  Off the chain, per pair:
+    two class reads (class*2) and pre = c1_2*C + c2_2; on the chain one v_lshl_add (address = 2e + pre, the table base
+    rides in the DS offset field) and one ds_read_u16.  mid = chain value after 32 symbols."""
+    L = []
+    ap = L.append
+    def cls_issue(j):
+        for k in (0, 1):
+            t = 2 * j + k
+            ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (t >> 2, SD, t & 3))
+            ap("ds_read_u8 %%[c%d%s], %%[x] offset:%d" % (j % 3, "ab"[k], PAIR_CLS2))
+    cls_issue(0)
+    cls_issue(1)
+    ap("s_waitcnt lgkmcnt(2)")
+    ap("v_mad_u32_u24 %[p0], %[c0a], %[C], %[c0b]")
+    ap("v_lshl_add_u32 %[x], %[e], 1, %[p0]")
+    ap("ds_read_u16 %%[e0], %%[x] offset:%d" % PAIR_TAB)
+    for j in range(32):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 2 < 32:
+            cls_issue(j + 2)
+        if j + 1 < 32:
+            # in flight, oldest first: classes of pair j+1 (2), e_j, classes of pair j+2 (2, if issued)
+            ap("s_waitcnt lgkmcnt(%d)" % (3 if j + 2 < 32 else 1))
+            ap("v_mad_u32_u24 %%[p%d], %%[c%da], %%[C], %%[c%db]" % (nxt, (j + 1) % 3, (j + 1) % 3))
+            ap("s_waitcnt lgkmcnt(%d)" % (2 if j + 2 < 32 else 0))
+            ap("v_lshl_add_u32 %%[x], %%[e%d], 1, %%[p%d]" % (cur, nxt))
+            ap("ds_read_u16 %%[e%d], %%[x] offset:%d" % (nxt, PAIR_TAB))
+        else:
+            ap("s_waitcnt lgkmcnt(0)")
+        if j == 15:
+            ap("v_mov_b32 %%[mid], %%[e%d]" % cur)
+        if j == 31:
+            ap("v_mov_b32 %%[e], %%[e%d]" % cur)
+    return L
+
+
+def main6(out):
+    out.write("constexpr uint32_t PAIR_CLS2 = %d, PAIR_TAB = %d;   // LDS layout of k_forward's pair mode (gen_sweeps.py)\n\n" % (PAIR_CLS2, PAIR_TAB))
+    tmp = ["e0", "e1", "c0a", "c0b", "c1a", "c1b", "c2a", "c2b", "p0", "p1", "x"]
+    emit_fn(out, "piece_run_pair",
+            "const uint32_t (&w)[16], uint32_t& e, uint32_t& mid, uint32_t C",
+            "uint32_t " + ", ".join(tmp) + ";",
+            run_pair(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[e] "+v"(e)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[C] "s"(C)'],
+            '"memory"')
+
+
 def emit_fn(out, name, sig, decl, lines, outs, ins, clob):
     out.write("__device__ __forceinline__ void %s(%s) {\n" % (name, sig))
     if decl:
@@ -528,3 +583,4 @@ if __name__ == "__main__":
     main3(sys.stdout)
     main4(sys.stdout)
     main5(sys.stdout)
+    main6(sys.stdout)

@@ -1,5 +1,6 @@
 """Timing probe (experiments, not the bench): one apache_log shard resident in HBM; prints kernel_ms of a run, or the
-wall time (events) of a run that ends in a match error (KX_DEBUG_FLAGS=2: k_forward fetches its input and takes no transition)."""
+wall time of a run that ends in a match error.  PERIODIC=1 makes every 32 KiB segment hold the same bytes (all lanes of a wave
+then read the same table rows: LDS reads without bank conflicts)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

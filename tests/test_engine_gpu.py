@@ -505,3 +505,24 @@ def test_tables_beyond_16_bit_addressing_run_from_global_memory(monkeypatch):
     for data in [b"a", b"abcab" * 50, b"c" * 64 + b"a" * 64, b"abc" * 3000]:
         got, want = both(blob, data, segment_bytes=64)
         assert got == want, len(data)
+
+
+def test_forward_walk_variants_agree(monkeypatch):
+    """k_forward's instances: two-symbol pair table + cooperative line loads (default where the tables fit LDS),
+    cooperative loads alone (`KX_NO_PAIR`), pair table with per-lane loads and the plain walk (`KX_NO_COOP`, + `KX_NO_PAIR`) —
+    same bytes and the same failure positions, on ragged sizes (trips of eight pieces are wave-uniform: lanes with short or
+    unsynchronised segments only help loading)."""
+    good = workloads.generate("apache_log", 500000, 41)
+    cut = good.index(b"\n", 300000) + 1
+    cases = [("apache_log", good), ("apache_log", good[:cut] + b"\n" + good[cut:]), ("apache_log", good[:cut + 33]),
+             ("csv2json", workloads.generate("csv", 300000, 42)), ("thousand_sep", workloads.generate("numbers", 200001, 43)),
+             ("flip_ab", b"ab" * 150000 + b"x" + b"ab" * 50), ("flip_ab", b"ab" * 70000)]
+    for env in ({}, {"KX_NO_PAIR": "1"}, {"KX_NO_COOP": "1"}, {"KX_NO_COOP": "1", "KX_NO_PAIR": "1"}):
+        for k in ("KX_NO_PAIR", "KX_NO_COOP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for prog, data in cases:
+            for seg in (512, 4096, 0):
+                got, want = both(blob_of(prog), data, segment_bytes=seg)
+                assert got == want, (env, prog, len(data), seg)

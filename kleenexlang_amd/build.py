@@ -81,7 +81,7 @@ def engine_sha():
     h = hashlib.sha256()
     d = os.path.join(CSRC, "engine")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".inc", ".py", ".cpp", ".h")):
+        if name.endswith((".hip", ".inc", ".py", ".h")):     # (the kernels and what generates them; not kxrun.cpp, the host driver)
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     with open(os.path.join(ROOT, "include", "kxp_format.h"), "rb") as f:

@@ -42,7 +42,9 @@ static std::string selfDir() {
 static int usage() {
   std::cout << "Usage: kexc compile [--quiet] [--opt N] [--la[=BOOL]] [--act[=BOOL]] [--copt N] [--cc CC]\n"
                "                    [--backend=hip|c] [--crt-dir DIR] [--srcout FILE] [--blob FILE] FILE.kex --out BIN\n"
-               "Subcommands simulate / interpret / visualize of the reference are not part of this build.\n";
+               "       kexc simulate|interpret [--sim lockstep|backtrack|sst] [--quiet] [--opt N] [--act[=BOOL]] FILE.kex  < in > out\n"
+               "                    (the program is compiled and run on the HIP engine; `interpret` = `simulate --quiet`)\n"
+               "The reference's `visualize` subcommand is not part of this build.\n";
   return 1;
 }
 
@@ -55,7 +57,7 @@ static bool parseBool(const std::string& v) {
 int main(int argc, char** argv) {
   std::vector<std::string> pos;
   Options o;
-  std::string crtdir, sub;
+  std::string crtdir, sub, sim = "lockstep";
   bool report = false;
   try {
     for (int i = 1; i < argc; ++i) {
@@ -73,6 +75,7 @@ int main(int argc, char** argv) {
       else if (key == "act") o.act = flag();
       else if (key == "func" || key == "sb" || key == "ite" || key == "rmidtbls" || key == "re") flag();
       else if (key == "metric" || key == "approxmode" || key == "wordsize") need();
+      else if (key == "sim") { sim = need(); if (sim != "lockstep" && sim != "backtrack" && sim != "sst") throw CompileError("\"" + sim + "\" is not a valid simulation type"); }
       else if (key == "copt") o.copt = std::stoi(need());
       else if (key == "out") o.out = need();
       else if (key == "srcout") o.srcout = need();
@@ -83,12 +86,41 @@ int main(int argc, char** argv) {
       else if (key == "help") return usage();
       else throw CompileError("unknown option --" + key);
     }
-    if (sub != "compile" || pos.size() != 1) return usage();
+    const bool simulate = sub == "simulate" || sub == "interpret";
+    if ((sub != "compile" && !simulate) || pos.size() != 1) return usage();
+    if (sub == "interpret") o.quiet = true;
     const std::string& file = pos[0];
     std::ifstream in(file, std::ios::binary);
     if (!in) { std::cerr << file << ": openFile: does not exist (No such file or directory)\n"; return 1; }
     std::stringstream ss; ss << in.rdbuf();
-    if (!o.quiet) std::cout << "Compile: " << file << " (direct mode; --la=false semantics)\n";
+    if (!o.quiet && !simulate) std::cout << "Compile: " << file << " (direct mode; --la=false semantics)\n";
+    if (simulate) {
+      // Commands.hs:277-323: stdin → the pipeline → stdout, whichever simulator is asked for — here every type is the
+      // compiled program on the HIP engine (their outputs are equal by the reference's own invariant, Tests/Regression.hs:45-53)
+      o.quiet = true;
+      Compiled cs = compileSource(ss.str(), file, o);
+      std::vector<uint8_t> sblob = writeBlob(cs.stages, cs.info);
+      const char* td = getenv("TMPDIR");
+      std::string path = std::string(td && *td ? td : "/tmp") + "/kexc-sim-XXXXXX";
+      int fd = mkstemp(&path[0]);
+      if (fd < 0) { std::cerr << "cannot create a temporary file in " << (td && *td ? td : "/tmp") << "\n"; return 1; }
+      close(fd);
+      int rc = 1;
+      try {
+        writeBinary(path, sblob, selfDir());
+        pid_t pid = fork();
+        if (pid == 0) {
+          setenv("KX_SIM_MESSAGES", sim.c_str(), 1);
+          const char* av[] = {path.c_str(), nullptr};
+          execv(path.c_str(), const_cast<char* const*>(av));
+          _exit(127);
+        }
+        int st = 0;
+        if (pid > 0) { waitpid(pid, &st, 0); rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1; }
+      } catch (...) { unlink(path.c_str()); throw; }
+      unlink(path.c_str());
+      return rc;
+    }
     Compiled c = compileSource(ss.str(), file, o);
     if (!o.quiet) {
       std::cout << "SST states: ";

@@ -37,7 +37,7 @@ for seed in range(int(os.environ.get("SOAK_LO", 300)), int(os.environ.get("SOAK_
     cands = []
     for k in (50, 400, 3000):
         cands.append(b"".join(rng.choice(pool) for _ in range(k)))
-    for seg in (64, 256, 4096):
+    for seg in (64, 1024, 4096):
         try:
             p = Program(blob, segment_bytes=seg)
         except Exception:

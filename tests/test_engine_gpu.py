@@ -526,3 +526,34 @@ def test_forward_walk_variants_agree(monkeypatch):
             for seg in (512, 4096, 0):
                 got, want = both(blob_of(prog), data, segment_bytes=seg)
                 assert got == want, (env, prog, len(data), seg)
+
+
+def test_kexc_simulate_runs_the_program_on_the_engine(tmp_path):
+    """`kexc simulate` / `interpret` (stdin → pipeline → stdout, Commands.hs:277-323).  Every `--sim` type is
+    the compiled program on the HIP engine; rejections use the reference simulators' words ("Reject" for the FST
+    simulations, Commands.hs:285; SymbolicSST.hs:425-427 for `--sim sst`), exit code 1, nothing on stdout."""
+    import subprocess
+    from kleenexlang_amd import build, program_path
+    kexc = os.path.join(build.OUT, "kexc")
+    data = workloads.generate("csv", 200000, 51)
+    want = oracle.run(blob_of("csv2json"), data)
+    for args in (["simulate"], ["simulate", "--sim", "backtrack"], ["interpret", "--sim=sst"], ["simulate", "--opt", "0", "--sim", "sst"]):
+        r = subprocess.run([kexc, *args, program_path("csv2json")], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == want, (args, r.stderr[-300:])
+    src = tmp_path / "two.kex"
+    two = 'start: a >> b\na := (/x/ "yy" | /y/ | /\\n/)*\nb := (~/y/ "z" | ~/x/ | /\\n/)*\n'
+    src.write_text(two)
+    r = subprocess.run([kexc, "simulate", str(src)], input=b"xyx\n" * 1000, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b"zzzzz\n" * 1000 == oracle.run(blob_of(two), b"xyx\n" * 1000), r.stderr
+    flip = program_path("flip_ab")
+    for sim, inp, msg in (("lockstep", b"abx", b"Reject\n"), ("backtrack", b"abx", b"Reject\n"), ("sst", b"abxab", b"No match\n"),
+                          ("sst", b"ab\n" * 3 + b"a", None)):
+        r = subprocess.run([kexc, "simulate", "--sim", sim, flip], input=inp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if msg is None:     # flip_ab accepts every prefix over {a, b, \\n}: accepted
+            assert r.returncode == 0
+        else:
+            assert r.returncode == 1 and r.stdout == b"" and r.stderr.endswith(msg), (sim, r.stderr)
+    eof = tmp_path / "eof.kex"
+    eof.write_text('main := /a/ /b/\n')
+    r = subprocess.run([kexc, "simulate", "--sim", "sst", str(eof)], input=b"a", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stderr.endswith(b"End of input reached, but final state is not accepting.\n"), r.stderr

@@ -98,3 +98,21 @@ def test_backend_c_paths_with_quotes_and_spaces_never_reach_a_shell(tmp_path):
     assert not (tmp_path / "pwned").exists()
     r = subprocess.run([str(out)], input=b"abba\n", stdout=subprocess.PIPE)
     assert r.stdout == b"baab\n"
+
+
+def test_simulate_subcommand_command_line(tmp_path):
+    """`kexc simulate|interpret [--sim lockstep|backtrack|sst] FILE` (src/kexc.hs:52-83, Options.hs:69-78): option checking
+    and parse errors are the compiler's; the run itself needs the HIP engine and says so when there is none (no CPU route)."""
+    r = run("simulate", "--sim", "bogus", program_path("flip_ab"))
+    assert r.returncode == 1 and b'"bogus" is not a valid simulation type' in r.stderr
+    bad = tmp_path / "bad.kex"; bad.write_text("main := (\n")
+    r = run("interpret", str(bad))
+    assert r.returncode == 1 and r.stdout == b"" and r.stderr
+    assert run("simulate").returncode == 1
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    r = run("simulate", "--sim=sst", program_path("flip_ab"), input=b"ab\n", env=env)
+    if r.returncode != 0:      # (CPU-only container: loud failure, nothing printed, the temporary binary is removed)
+        assert r.stdout == b"" and b"no HIP device" in r.stderr or b"cannot load the HIP engine" in r.stderr
+    else:
+        assert r.stdout == b"ba\n"
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("kexc-sim-")]

@@ -98,6 +98,18 @@ int kexc_emit_c(const char* source, size_t source_len, const char* source_name, 
  * [{"nstates","init","final":[..],"eps":[[ [[out bytes],to], ..] per state],"sym":[[ [[[lo,hi],..],copy,to], ..] per state]}] */
 int kexc_dump_fst(const char* source, size_t source_len, const char* source_name, char** json, size_t* json_len);
 
+/* Regex flavour — what `kexc compile FILE.re|FILE.rx` / `kexc compile --re EXPR` builds (src/kexc.hs:46-48;
+ * createProgram's RegexFlavor branch, generateOracleSSTs, compileCoder: src/KMC/Frontend/Commands.hs:69-79,117-136,
+ * 246-275): the program that reads a string matching the (anchored) regular expression and writes the code of its greedy
+ * parse — one base-256 digit for every choice the parse makes (the index of the ε-alternative taken, the index of the
+ * symbol within a predicate with more than one member; src/KMC/SymbolicFST/OracleMachine.hs:47-61 with digit = Word8,
+ * src/KMC/Frontend.hs:117).  Same blob format, same engine. */
+int kexc_compile_regex(const char* regex, size_t regex_len, const char* source_name, int opt_level,
+                       unsigned char** blob, size_t* blob_len);
+
+/* Test support: the regex's transducer (oracle = 0) or its oracle machine (oracle = 1), JSON as kexc_dump_fst. */
+int kexc_dump_regex_fst(const char* regex, size_t regex_len, int oracle, char** json, size_t* json_len);
+
 const char* kexc_last_error(void);
 void kexc_free(void* p);
 

@@ -135,6 +135,43 @@ FST constructTransducer(const RProg& rp, int start, bool tokens) {
   return f;
 }
 
+// OracleMachine.hs:47-61.  `symsym`: a copying symbol edge over a predicate p with more than one member outputs the
+// fixed-width code of the symbol's index in p (CodeArg p), every other symbol edge outputs nothing; `epseps`: the k-th of
+// n > 1 ε-alternatives outputs the fixed-width code of k, a lone ε-edge nothing.  Digits are base 256 (Frontend.hs:117),
+// so a code is one byte up to 256 alternatives (Util/Coding.hs:13-19,66-73: width = least w with 256^w >= n, big-endian).
+// The engine's tables have no symbol-indexed output function, so CodeArg p leaves as |p| single-symbol edges, each
+// followed by a lone ε-edge carrying that symbol's code — the same relation, symbol for symbol.
+FST oracleTransducer(const FST& f) {
+  auto code = [](int n, int k) {
+    int w = 0; long long cap = 1;
+    while (cap < n) { cap *= 256; ++w; }
+    std::string c((size_t)w, '\0');
+    for (int i = w - 1; i >= 0; --i) { c[(size_t)i] = char(k & 0xFF); k >>= 8; }
+    return c;
+  };
+  FST o;
+  o.nstates = f.nstates; o.init = f.init; o.is_final = f.is_final;
+  o.eps.resize((size_t)f.nstates); o.sym.resize((size_t)f.nstates);
+  auto fresh = [&]() { o.eps.emplace_back(); o.sym.emplace_back(); o.is_final.push_back(0); return o.nstates++; };
+  for (int q = 0; q < f.nstates; ++q) {
+    const auto& es = f.eps[(size_t)q];
+    for (size_t k = 0; k < es.size(); ++k)
+      o.eps[(size_t)q].push_back({es.size() > 1 ? code((int)es.size(), (int)k) : std::string(), es[k].to});
+    for (const auto& e : f.sym[(size_t)q]) {
+      const int n = e.pred.size();
+      if (!e.copy || n <= 1) { o.sym[(size_t)q].push_back({e.pred, false, e.to}); continue; }
+      int idx = 0;
+      for (int x = 0; x < 256; ++x) {
+        if (!e.pred.has(x)) continue;
+        const int s = fresh();
+        o.sym[(size_t)q].push_back({ByteSet::single(x), false, s});
+        o.eps[(size_t)s].push_back({code(n, idx++), e.to});
+      }
+    }
+  }
+  return o;
+}
+
 // =============================================================== path trees
 namespace {
 

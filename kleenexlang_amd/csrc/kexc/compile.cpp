@@ -17,6 +17,20 @@ namespace kexc {
 
 Compiled compileSource(const std::string& src, const std::string& srcname, const Options& o) {
   Compiled out;
+  if (o.regex) {
+    // createProgram (RegexFlavor) → buildTransducers → generateOracleSSTs → compileCoder (Commands.hs:69-79,117-136,246-275;
+    // kexc.hs:46-48): the program's output is the code of the greedy parse, not a rewriting of the input
+    RProg rp = parseRegexProgram(src, srcname);
+    FST f = oracleTransducer(constructTransducer(rp, rp.pipeline[0], false));
+    SST sst = determinize(f);
+    optimizeSST(sst, o.opt);
+    out.sst_states.push_back((int)sst.states.size());
+    out.stages.push_back(lower(sst, sst));
+    std::ostringstream info;                  // Commands.hs:258-266
+    info << "Options:\\n--opt " << o.opt << " --la=false --wordsize 8\\n\\nSource file: " << srcname << "\\nOracle SST states:  " << out.sst_states[0];
+    out.info = info.str();
+    return out;
+  }
   Prog ast = parseKleenex(src, srcname);
   RProg rp = desugar(ast);
   for (int start : rp.pipeline) {
@@ -96,6 +110,38 @@ int kexc_emit_c(const char* source, size_t source_len, const char* source_name, 
 
 // The nondeterministic transducer of every pipeline stage as JSON — for tests that simulate the FST
 // directly (an evaluation route that shares nothing with determinization, lowering or the engines).
+static void fstJson(std::ostringstream& o, const kexc::FST& f, bool toks) {
+  o << "{\"tokens\":" << (toks ? "true" : "false") << ",\"nstates\":" << f.nstates << ",\"init\":" << f.init << ",\"final\":[";
+  bool first = true;
+  for (int q = 0; q < f.nstates; ++q) if (f.is_final[q]) { o << (first ? "" : ",") << q; first = false; }
+  o << "],\"eps\":[";
+  for (int q = 0; q < f.nstates; ++q) {
+    o << (q ? "," : "") << "[";
+    for (size_t k = 0; k < f.eps[q].size(); ++k) {
+      o << (k ? "," : "") << "[[";
+      for (size_t b = 0; b < f.eps[q][k].out.size(); ++b) o << (b ? "," : "") << (int)(unsigned char)f.eps[q][k].out[b];
+      o << "]," << f.eps[q][k].to << "]";
+    }
+    o << "]";
+  }
+  o << "],\"sym\":[";
+  for (int q = 0; q < f.nstates; ++q) {
+    o << (q ? "," : "") << "[";
+    for (size_t k = 0; k < f.sym[q].size(); ++k) {
+      o << (k ? "," : "") << "[[";
+      bool fr = true;
+      for (int b = 0; b < 256;) {
+        if (!f.sym[q][k].pred.has(b)) { ++b; continue; }
+        int e = b; while (e + 1 < 256 && f.sym[q][k].pred.has(e + 1)) ++e;
+        o << (fr ? "" : ",") << "[" << b << "," << e << "]"; fr = false; b = e + 1;
+      }
+      o << "]," << (f.sym[q][k].copy ? 1 : 0) << "," << f.sym[q][k].to << "]";
+    }
+    o << "]";
+  }
+  o << "]}";
+}
+
 int kexc_dump_fst(const char* source, size_t source_len, const char* source_name, char** json, size_t* json_len) {
   try {
     std::string name = source_name ? source_name : "<memory>";
@@ -106,36 +152,45 @@ int kexc_dump_fst(const char* source, size_t source_len, const char* source_name
     for (size_t si = 0; si < rp.pipeline.size(); ++si) {
       const bool toks = kexc::stageHasActions(rp, rp.pipeline[si]);
       kexc::FST f = kexc::constructTransducer(rp, rp.pipeline[si], toks);
-      o << (si ? "," : "") << "{\"tokens\":" << (toks ? "true" : "false") << ",\"nstates\":" << f.nstates << ",\"init\":" << f.init << ",\"final\":[";
-      bool first = true;
-      for (int q = 0; q < f.nstates; ++q) if (f.is_final[q]) { o << (first ? "" : ",") << q; first = false; }
-      o << "],\"eps\":[";
-      for (int q = 0; q < f.nstates; ++q) {
-        o << (q ? "," : "") << "[";
-        for (size_t k = 0; k < f.eps[q].size(); ++k) {
-          o << (k ? "," : "") << "[[";
-          for (size_t b = 0; b < f.eps[q][k].out.size(); ++b) o << (b ? "," : "") << (int)(unsigned char)f.eps[q][k].out[b];
-          o << "]," << f.eps[q][k].to << "]";
-        }
-        o << "]";
-      }
-      o << "],\"sym\":[";
-      for (int q = 0; q < f.nstates; ++q) {
-        o << (q ? "," : "") << "[";
-        for (size_t k = 0; k < f.sym[q].size(); ++k) {
-          o << (k ? "," : "") << "[[";
-          bool fr = true;
-          for (int b = 0; b < 256;) {
-            if (!f.sym[q][k].pred.has(b)) { ++b; continue; }
-            int e = b; while (e + 1 < 256 && f.sym[q][k].pred.has(e + 1)) ++e;
-            o << (fr ? "" : ",") << "[" << b << "," << e << "]"; fr = false; b = e + 1;
-          }
-          o << "]," << (f.sym[q][k].copy ? 1 : 0) << "," << f.sym[q][k].to << "]";
-        }
-        o << "]";
-      }
-      o << "]}";
+      o << (si ? "," : "");
+      fstJson(o, f, toks);
     }
+    o << "]";
+    std::string txt = o.str();
+    *json = dupBytes(txt.data(), txt.size());
+    *json_len = txt.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+// Regex flavour (`.re` / `.rx` / `--re`): the bit-coder — kexc.hs:46-48 → generateOracleSSTs → compileCoder.
+int kexc_compile_regex(const char* regex, size_t regex_len, const char* source_name, int opt_level,
+                       unsigned char** blob, size_t* blob_len) {
+  try {
+    kexc::Options o; o.opt = opt_level; o.regex = true;
+    auto c = kexc::compileSource(std::string(regex, regex_len), source_name ? source_name : "<command line>", o);
+    auto b = kexc::writeBlob(c.stages, c.info);
+    *blob = (unsigned char*)dupBytes(b.data(), b.size());
+    *blob_len = b.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+// flavour 0: the regex's transducer before `oracle` (symbols copied); 1: its oracle machine
+int kexc_dump_regex_fst(const char* regex, size_t regex_len, int oracle, char** json, size_t* json_len) {
+  try {
+    kexc::RProg rp = kexc::parseRegexProgram(std::string(regex, regex_len), "<command line>");
+    kexc::FST f = kexc::constructTransducer(rp, rp.pipeline[0], false);
+    if (oracle) f = kexc::oracleTransducer(f);
+    std::ostringstream o;
+    o << "[";
+    fstJson(o, f, false);
     o << "]";
     std::string txt = o.str();
     *json = dupBytes(txt.data(), txt.size());

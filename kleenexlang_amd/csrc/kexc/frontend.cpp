@@ -40,6 +40,7 @@ struct Parser {
   const std::string& s;
   const std::string& srcname;
   size_t p = 0;
+  bool re_top = false;   // the source is one regular expression (regex flavour): it ends at end of input, '/' is illegal
   Parser(const std::string& src, const std::string& name) : s(src), srcname(name) {}
 
   [[noreturn]] void err(const std::string& m) { fail(srcname, s, p, m); }
@@ -227,7 +228,7 @@ struct Parser {
     while (!eof() && peek() != '/' && peek() != '|' && peek() != ')') {
       // an unescaped '$' that closes the literal is the end anchor (anchoredRegexP, Parser.hs:204-206, strips both
       // anchors: Kleenex terms are anchored anyway), not a byte to match
-      if (peek() == '$' && p + 1 < s.size() && s[p + 1] == '/') { ++p; break; }
+      if (peek() == '$' && (re_top ? p + 1 == s.size() : p + 1 < s.size() && s[p + 1] == '/')) { ++p; break; }
       RegexP r = regexRepeat();
       acc = acc ? mk2(Regex::Concat, acc, r) : r;
     }
@@ -242,6 +243,14 @@ struct Parser {
     if (peek() == '^') ++p;  // anchors are implicit for Kleenex terms
     RegexP r = regexAlt();
     if (peek() != '/') err("expecting '/' to close regex");
+    return r;
+  }
+
+  RegexP regexWhole() {  // regexP <* eof (Parser.hs:204-206,229-230)
+    re_top = true;
+    if (peek() == '^') ++p;
+    RegexP r = regexAlt();
+    if (!eof()) err(peek() == '/' ? "unexpected '/' in regular expression" : "unexpected character in regular expression");
     return r;
   }
 
@@ -527,6 +536,17 @@ struct Desugarer {
 };
 
 }  // namespace
+
+RProg parseRegexProgram(const std::string& src, const std::string& srcname) {
+  Parser ps(src, srcname);
+  RegexP r = ps.regexWhole();
+  Desugarer d;                       // desugarRegex (Desugaring.hs:231-239): fresh identifiers from 0, symbols written
+  int start = d.re(true, r);
+  RProg rp;
+  rp.pipeline.push_back(start);
+  rp.decls = std::move(d.decls);
+  return rp;
+}
 
 RProg desugar(const Prog& p) {  // Desugaring.hs:173-207
   Desugarer d;

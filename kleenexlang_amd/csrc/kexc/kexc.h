@@ -97,6 +97,9 @@ struct RTerm {  // Kleenex/Syntax.hs:95-102
 };
 struct RProg { std::vector<int> pipeline; std::map<int, RTerm> decls; std::vector<std::string> regnames; };
 RProg desugar(const Prog& p);
+// regex flavour (`.re` / `.rx` / `--re`): the whole source is one regular expression (parseRegex, Kleenex/Parser.hs:204-206,
+// 229-230) desugared with output enabled (desugarRegex, Desugaring.hs:231-239)
+RProg parseRegexProgram(const std::string& src, const std::string& srcname);
 
 // ---------------------------------------------------------------- the FST
 struct FST {  // SymbolicFST.hs:49-55; states are ints after enumerateStates
@@ -111,6 +114,9 @@ struct FST {  // SymbolicFST.hs:49-55; states are ints after enumerateStates
 bool stageHasActions(const RProg& rp, int start);
 // tokens = false: direct mode, fails on register actions; true: actions and the byte 0xFF leave as escape tokens (automata.cpp)
 FST constructTransducer(const RProg& rp, int start, bool tokens = false);
+// the oracle of a transducer (SymbolicFST/OracleMachine.hs:47-61): symbol outputs dropped, every nondeterministic choice
+// coded — one base-256 digit per choice, as the front end instantiates it (Frontend.hs:117: digit = Word8)
+FST oracleTransducer(const FST& f);
 
 // ---------------------------------------------------------------- the SST
 struct Atom {  // SymbolicSST.hs:52-56
@@ -175,6 +181,8 @@ struct Options {
   int opt = 3; bool la = true; bool act = true; bool quiet = false;
   std::string out, srcout, cc = "cc", backend = "hip", blobout;
   int copt = 3;
+  bool regex = false;          // regex flavour: the bit-coder (kexc.hs:46-48, compileCoder Commands.hs:246-275)
+  int wordsize = 8;            // --wordsize: the run-time buffer unit (Options.hs:130-144); only 8 produces defined output, see main.cpp
 };
 struct Compiled { std::vector<StageTables> stages; std::string info; std::vector<int> sst_states; };
 Compiled compileSource(const std::string& src, const std::string& srcname, const Options& o);

@@ -41,7 +41,9 @@ static std::string selfDir() {
 
 static int usage() {
   std::cout << "Usage: kexc compile [--quiet] [--opt N] [--la[=BOOL]] [--act[=BOOL]] [--copt N] [--cc CC]\n"
-               "                    [--backend=hip|c] [--crt-dir DIR] [--srcout FILE] [--blob FILE] FILE.kex --out BIN\n"
+               "                    [--backend=hip|c] [--crt-dir DIR] [--srcout FILE] [--blob FILE] [--wordsize 8] FILE.kex --out BIN\n"
+               "       kexc compile … FILE.re|FILE.rx --out BIN   |   kexc compile … --re 'REGEX' --out BIN\n"
+               "                    (regex flavour: BIN writes the code of the greedy parse, one byte per choice)\n"
                "       kexc simulate|interpret [--sim lockstep|backtrack|sst] [--quiet] [--opt N] [--act[=BOOL]] FILE.kex  < in > out\n"
                "                    (the program is compiled and run on the HIP engine; `interpret` = `simulate --quiet`)\n"
                "The reference's `visualize` subcommand is not part of this build.\n";
@@ -58,7 +60,7 @@ int main(int argc, char** argv) {
   std::vector<std::string> pos;
   Options o;
   std::string crtdir, sub, sim = "lockstep";
-  bool report = false;
+  bool report = false, expr = false;
   try {
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
@@ -73,8 +75,14 @@ int main(int argc, char** argv) {
       else if (key == "opt") o.opt = std::stoi(need());
       else if (key == "la") o.la = flag();
       else if (key == "act") o.act = flag();
-      else if (key == "func" || key == "sb" || key == "ite" || key == "rmidtbls" || key == "re") flag();
-      else if (key == "metric" || key == "approxmode" || key == "wordsize") need();
+      else if (key == "re") expr = flag();                  // the argument is the regular expression itself (Options.hs optExpressionArg)
+      else if (key == "func" || key == "sb" || key == "ite" || key == "rmidtbls") flag();
+      else if (key == "wordsize") {                         // Options.hs:130-144
+        const std::string w = need();
+        if (w != "8" && w != "16" && w != "32" && w != "64") throw CompileError("\"" + w + "\" is not a valid word size");
+        o.wordsize = std::stoi(w);
+      }
+      else if (key == "metric" || key == "approxmode") need();
       else if (key == "sim") { sim = need(); if (sim != "lockstep" && sim != "backtrack" && sim != "sst") throw CompileError("\"" + sim + "\" is not a valid simulation type"); }
       else if (key == "copt") o.copt = std::stoi(need());
       else if (key == "out") o.out = need();
@@ -90,15 +98,33 @@ int main(int argc, char** argv) {
     if ((sub != "compile" && !simulate) || pos.size() != 1) return usage();
     if (sub == "interpret") o.quiet = true;
     const std::string& file = pos[0];
-    std::ifstream in(file, std::ios::binary);
-    if (!in) { std::cerr << file << ": openFile: does not exist (No such file or directory)\n"; return 1; }
-    std::stringstream ss; ss << in.rdbuf();
-    if (!o.quiet && !simulate) std::cout << "Compile: " << file << " (direct mode; --la=false semantics)\n";
+    if (o.wordsize != 8) {
+      // The reference always compiles with -D FLAG_WORDALIGNED (kexc.hs:40-48 pass True; C.hs:567), under which a write of
+      // fewer bits than the buffer unit does not advance to the next unit (crt.c:143-155): with 8-bit symbols a unit wider
+      // than 8 bits makes successive writes overwrite each other.  There is no defined output to reproduce.
+      std::cerr << "--wordsize " << o.wordsize << ": only a buffer unit of 8 bits gives defined output for 8-bit symbols (the reference's word-aligned "
+                   "runtime overwrites partial units, crt/crt.c:143-155); use --wordsize 8\n";
+      return 1;
+    }
+    std::stringstream ss;
+    std::string srcname = file;
+    if (expr) { ss << file; srcname = "<command line>"; o.regex = true; }   // Commands.hs:70-72
+    else {
+      // getCompileFlavor (Frontend.hs:140-152)
+      const size_t slash = file.find_last_of('/'), dot = file.find_last_of('.');
+      const std::string ext = dot == std::string::npos || (slash != std::string::npos && dot < slash) ? "" : file.substr(dot);
+      if (ext == ".re" || ext == ".rx") o.regex = true;
+      else if (ext != ".kex") { std::cerr << "Unknown extension: '" << ext << "'.\nExpects one of '.kex', '.re', or '.rx'.\n"; return 1; }
+      std::ifstream in(file, std::ios::binary);
+      if (!in) { std::cerr << file << ": openFile: does not exist (No such file or directory)\n"; return 1; }
+      ss << in.rdbuf();
+    }
+    if (!o.quiet && !simulate) std::cout << "Compile: " << srcname << (o.regex ? " (regex flavour: bit-coder; --la=false semantics)\n" : " (direct mode; --la=false semantics)\n");
     if (simulate) {
       // Commands.hs:277-323: stdin → the pipeline → stdout, whichever simulator is asked for — here every type is the
       // compiled program on the HIP engine (their outputs are equal by the reference's own invariant, Tests/Regression.hs:45-53)
       o.quiet = true;
-      Compiled cs = compileSource(ss.str(), file, o);
+      Compiled cs = compileSource(ss.str(), srcname, o);
       std::vector<uint8_t> sblob = writeBlob(cs.stages, cs.info);
       const char* td = getenv("TMPDIR");
       std::string path = std::string(td && *td ? td : "/tmp") + "/kexc-sim-XXXXXX";
@@ -121,9 +147,9 @@ int main(int argc, char** argv) {
       unlink(path.c_str());
       return rc;
     }
-    Compiled c = compileSource(ss.str(), file, o);
+    Compiled c = compileSource(ss.str(), srcname, o);
     if (!o.quiet) {
-      std::cout << "SST states: ";
+      std::cout << (o.regex ? "Oracle SST states: " : "SST states: ");
       for (size_t i = 0; i < c.sst_states.size(); ++i) std::cout << (i ? ", " : "") << c.sst_states[i];
       std::cout << "\n";
     }

@@ -187,6 +187,42 @@ def dump_fst(source, name="<memory>"):
         lib.kexc_free(txt)
 
 
+def compile_regex(regex, name="<command line>", opt=3):
+    """Regular expression → KXP blob of its bit-coder (``kexc compile --re EXPR`` / ``FILE.re``; Commands.hs:246-275)."""
+    lib = load_compiler()
+    if isinstance(regex, str):
+        regex = regex.encode("utf-8")
+    blob = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    lib.kexc_compile_regex.argtypes = lib.kexc_compile.argtypes
+    rc = lib.kexc_compile_regex(regex, len(regex), name.encode(), opt, ctypes.byref(blob), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return ctypes.string_at(blob, n.value)
+    finally:
+        lib.kexc_free(blob)
+
+
+def dump_regex_fst(regex, oracle=True):
+    """JSON-decoded transducer of a regex program: its oracle machine, or (oracle=False) the transducer before `oracle`."""
+    import json
+    lib = load_compiler()
+    if isinstance(regex, str):
+        regex = regex.encode("utf-8")
+    txt = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    lib.kexc_dump_regex_fst.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_size_t)]
+    rc = lib.kexc_dump_regex_fst(regex, len(regex), 1 if oracle else 0, ctypes.byref(txt), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return json.loads(ctypes.string_at(txt, n.value).decode("utf-8"))
+    finally:
+        lib.kexc_free(txt)
+
+
 def validate_blob(blob):
     """Structural check of a KXP blob (no device needed).  Raises EngineError with the engine's message."""
     lib = load_engine()

@@ -283,7 +283,7 @@ def test_coder_on_the_engine():
                 with pytest.raises(host.MatchError):
                     prog.run_host(data)
             else:
-                assert prog.run_host(data)[0] == want, (regex, data)
+                assert prog.run_host(data) == want, (regex, data)
         prog.close()
     rnd = random.Random(7)
     fields = [bytes(rnd.choice(b"abcdefghij0123456789 ") for _ in range(rnd.randrange(0, 12))) for _ in range(4096)]
@@ -294,10 +294,37 @@ def test_coder_on_the_engine():
     assert len(want) > len(rows) // 2
     for seg in (0, 4096, 65536):
         prog = host.Program(blob, segment_bytes=seg)
-        assert prog.run_host(rows)[0] == want
+        assert prog.run_host(rows) == want
         prog.close()
     big = rows * (64 * 1024 * 1024 // len(rows))
     prog = host.Program(blob)
-    got = prog.run_host(big)[0]
+    got = prog.run_host(big)
     assert got == want[:-1] * (len(big) // len(rows)) + want[-1:]   # (every row's code, then the final "leave the loop")
     prog.close()
+
+
+@pytest.mark.gpu
+def test_coder_binary_and_simulate(tmp_path):
+    """The produced binary of a `.rx` file (`BIN < in > out`, windowed) and `kexc simulate --re EXPR` (simulateCoder,
+    Commands.hs:317-322) write the same code as the CPU oracle; a string outside the language is a match error."""
+    from kleenexlang_amd import build
+    kexc = os.path.join(build.OUT, "kexc")
+    regex = "(([a-z]*|[0-9]+)(,|\\n))*"
+    rnd = random.Random(11)
+    data = b"".join(rnd.choice([b"abc", b"", b"0042", b"z", b"7"]) + rnd.choice([b",", b"\n"]) for _ in range(300000))
+    want = oracle.run(host.compile_regex(regex), data)
+    assert greedy_code(regex, data[:40] + b"\n") == oracle.run(host.compile_regex(regex), data[:40] + b"\n")
+    rx = tmp_path / "fields.rx"
+    rx.write_text(regex)
+    binp = tmp_path / "fields_bin"
+    r = subprocess.run([kexc, "compile", "--quiet", str(rx), "--out", str(binp)], stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    for env in ({}, {"KX_WINDOW_BYTES": "65536"}):
+        r = subprocess.run([str(binp)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, **env})
+        assert r.returncode == 0 and r.stdout == want, (env, r.stderr[-300:])
+    r = subprocess.run([kexc, "simulate", "--re", regex], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == want, r.stderr[-300:]
+    r = subprocess.run([str(binp)], input=b"abc,DEF\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"Match error at input symbol 4!" in r.stderr, r.stderr
+    r = subprocess.run([str(binp), "-i"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert b"Oracle SST states" in r.stdout, r.stdout

@@ -30,8 +30,8 @@ extern "C" {
  *   delta/action  per (block, class): GotoI target (0xFFFF = FailI) and the register updates, as an index into `actions`
  *   final_action  the NextI fallback: updates then AcceptI; 0xFFFFFFFF = FailI
  *   actions       ordered micro-ops {op << 24 | dst register, arg}: 0 ResetI dst; 1 AppendI dst, constant arg;
- *                 2 AppendSymI dst (the current input byte); 3 ConcatI dst, register arg      (IL.hs:40-47; register 0 =
- *                 progStreamBuffer, the output)
+ *                 2 AppendSymI dst (the current input byte); 3 ConcatI dst, register arg; 4 AppendTblI dst, table arg
+ *                 (below)      (IL.hs:40-47; register 0 = progStreamBuffer, the output)
  *   constants     progConstants as offsets into one pool (const_off[nconsts+1])
  * The annotation is what the determinizer knows when it builds a transition (Determinization.hs:165-177, TreeWriter.hs)
  * and the IL no longer says: which leaf of the SOURCE state's path tree each leaf of the TARGET state extends, and by
@@ -57,6 +57,14 @@ typedef struct kexc_il_program {
   /* register actions: non-zero = the program's output is a token stream (escape byte 0xFF: FF FF = byte FF, FF 00 Push,
    * FF 01 r Pop r, FF 02 r Write r; kxp_format.h) to be replayed by the action interpreter with `action_regs` registers */
   uint32_t has_actions, action_regs;
+  /* AppendTblI (src/KMC/Program/IL.hs:44,84 progTables; built by SSTCompiler/Classes.hs:102-125 for the coder's
+   * `CodeArg p`; printed by C.hs:421-430): micro-op 4 = AppendTblI dst, table arg — appends tables[arg][next[0]], a string
+   * of tbl_width[arg] digits (bytes: progOutBits = 8).  Table t starts at tbl_data + 256 * (tbl_width[0] + … +
+   * tbl_width[t-1]); the entry of symbol s lies at + s * tbl_width[t].  In the annotation, back_table[row*maxleaves + leaf]
+   * names the table whose entry for the symbol read is appended on that path step BEFORE the path constant (0xFFFFFFFF =
+   * none; not together with the copy bit); NULL when ntables == 0.  The engine's tables hold no symbol-indexed output:
+   * kexc_emit_pipeline refines the byte classes until every table is constant on each class and turns op 4 into op 1. */
+  uint32_t ntables; const uint32_t* tbl_width; const uint8_t* tbl_data; const uint32_t* back_table;
 } kexc_il_program;
 
 /* `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per

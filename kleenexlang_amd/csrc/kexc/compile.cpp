@@ -234,19 +234,111 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
         if (P.pconst_off[c + 1] < P.pconst_off[c]) bad("path constant offsets out of order");
         t.pconsts.emplace_back((const char*)P.pconst_pool + P.pconst_off[c], P.pconst_off[c + 1] - P.pconst_off[c]);
       }
+      if (P.ntables && (!P.tbl_width || !P.tbl_data || !P.back_table)) bad("missing table data");
+      std::vector<size_t> tbl_at(P.ntables, 0);
+      for (uint32_t k = 0, at = 0; k < P.ntables; ++k) { if (P.tbl_width[k] > 8) bad("table digits wider than 8"); tbl_at[k] = at; at += 256 * P.tbl_width[k]; }
+      auto tblEntry = [&](uint32_t k, int sym) { return std::string((const char*)P.tbl_data + tbl_at[k] + (size_t)sym * P.tbl_width[k], P.tbl_width[k]); };
+      bool uses_tables = false;
       for (uint32_t a = 0; a < P.nactions; ++a) {
         if (P.action_off[a + 1] < P.action_off[a]) bad("action offsets out of order");
         std::vector<MicroOp> ops;
         for (uint32_t k = P.action_off[a]; k < P.action_off[a + 1]; ++k) {
           const uint32_t w0 = P.ops[2 * k], arg = P.ops[2 * k + 1], op = w0 >> 24, dst = w0 & 0xFFFFFF;
-          if (op > 3 || dst >= P.nregs || (op == 1 && arg >= P.nconsts) || (op == 3 && arg >= P.nregs)) bad("malformed micro-op");
+          if (op > 4 || dst >= P.nregs || (op == 1 && arg >= P.nconsts) || (op == 3 && arg >= P.nregs) || (op == 4 && arg >= P.ntables)) bad("malformed micro-op");
+          uses_tables |= op == 4;
           ops.push_back(MicroOp{(uint8_t)op, (uint16_t)dst, arg});
         }
         t.actions.push_back(ops);
       }
-      for (size_t i = 0; i < sc; ++i) {
+      t.back.assign(P.back, P.back + (size_t)P.nback * P.maxleaves);
+      std::vector<uint32_t> btab(t.back.size(), 0xFFFFFFFFu);
+      if (P.ntables) {
+        btab.assign(P.back_table, P.back_table + t.back.size());
+        for (size_t i = 0; i < btab.size(); ++i)
+          if (btab[i] != 0xFFFFFFFFu) {
+            if (btab[i] >= P.ntables || t.back[i] == 0xFFFFFFFFu || ((t.back[i] >> 8) & 1)) bad("backward table entry out of range");
+            uses_tables = true;
+          }
+      }
+      for (uint32_t q = 0; q < P.nstates; ++q)
+        if (t.final_act[q] != 0xFFFFFFFFu && t.final_act[q] < P.nactions)
+          for (auto& m : t.actions[t.final_act[q]]) if (m.op == 4) bad("AppendTblI in a final action (no symbol to index with)");
+      if (uses_tables) {
+        // AppendTblI → AppendI: refine the byte classes until every table is constant on each class, then give each
+        // (state, class) its own copy of the action / backward row with the table entries written out as constants
+        for (size_t i = 0; i < sc; ++i) if (t.delta[i] != 0xFFFF && (t.act[i] >= P.nactions || t.pback[i] >= P.nback)) bad("transition out of range");
+        std::map<std::string, int> sig2cls;
+        uint8_t ncls[256]; std::vector<int> rep, oldc;
+        for (int b = 0; b < 256; ++b) {
+          std::string sig(1, (char)t.cls[b]);
+          for (uint32_t k = 0; k < P.ntables; ++k) sig += tblEntry(k, b);
+          auto it = sig2cls.find(sig);
+          if (it == sig2cls.end()) { it = sig2cls.emplace(sig, (int)rep.size()).first; rep.push_back(b); oldc.push_back(t.cls[b]); }
+          ncls[b] = (uint8_t)it->second;
+        }
+        const int NC = (int)rep.size();
+        std::map<std::string, uint32_t> constId, pconstId;
+        for (uint32_t c = 0; c < t.consts.size(); ++c) constId.emplace(t.consts[c], c);
+        for (uint32_t c = 0; c < t.pconsts.size(); ++c) pconstId.emplace(t.pconsts[c], c);
+        auto internC = [&](const std::string& v) { auto it = constId.find(v); if (it != constId.end()) return it->second; t.consts.push_back(v); return constId[v] = (uint32_t)t.consts.size() - 1; };
+        auto internP = [&](const std::string& v) { auto it = pconstId.find(v); if (it != pconstId.end()) return it->second; t.pconsts.push_back(v); return pconstId[v] = (uint32_t)t.pconsts.size() - 1; };
+        std::map<std::pair<uint32_t, std::string>, uint32_t> actMemo, rowMemo;
+        std::vector<uint16_t> nd((size_t)P.nstates * NC, 0xFFFF);
+        std::vector<uint32_t> na(nd.size(), 0), nb(nd.size(), 0);
+        const uint32_t ML = P.maxleaves;
+        for (uint32_t q = 0; q < P.nstates; ++q)
+          for (int c = 0; c < NC; ++c) {
+            const size_t o = (size_t)q * P.nclasses + oldc[c], n = (size_t)q * NC + c;
+            nd[n] = t.delta[o];
+            if (nd[n] == 0xFFFF) continue;
+            std::string key;
+            for (uint32_t k = 0; k < P.ntables; ++k) key += tblEntry(k, rep[c]) + '\x01';
+            {
+              bool any = false;
+              for (auto& m : t.actions[t.act[o]]) any |= m.op == 4;
+              if (!any) na[n] = t.act[o];
+              else {
+                auto it = actMemo.find({t.act[o], key});
+                if (it == actMemo.end()) {
+                  std::vector<MicroOp> ops = t.actions[t.act[o]];
+                  for (auto& m : ops) if (m.op == 4) { m.arg = internC(tblEntry(m.arg, rep[c])); m.op = 1; }
+                  t.actions.push_back(ops);
+                  it = actMemo.emplace(std::make_pair(t.act[o], key), (uint32_t)t.actions.size() - 1).first;
+                }
+                na[n] = it->second;
+              }
+            }
+            {
+              const uint32_t row = t.pback[o];
+              bool any = false;
+              for (uint32_t l = 0; l < ML; ++l) any |= btab[(size_t)row * ML + l] != 0xFFFFFFFFu;
+              if (!any) nb[n] = row;
+              else {
+                auto it = rowMemo.find({row, key});
+                if (it == rowMemo.end()) {
+                  const uint32_t nr = (uint32_t)(t.back.size() / ML);
+                  for (uint32_t l = 0; l < ML; ++l) {
+                    uint32_t e = t.back[(size_t)row * ML + l];
+                    const uint32_t tb = btab[(size_t)row * ML + l];
+                    if (tb != 0xFFFFFFFFu) {
+                      if ((e >> 9) >= P.npconsts) bad("backward entry out of range");
+                      e = (e & 0x1FF) | (internP(tblEntry(tb, rep[c]) + t.pconsts[e >> 9]) << 9);
+                    }
+                    t.back.push_back(e);
+                  }
+                  it = rowMemo.emplace(std::make_pair(row, key), nr).first;
+                }
+                nb[n] = it->second;
+              }
+            }
+          }
+        t.nclasses = NC; memcpy(t.cls, ncls, 256);
+        t.delta = std::move(nd); t.act = std::move(na); t.pback = std::move(nb);
+      }
+      const size_t sc2 = (size_t)t.nstates * t.nclasses, nback2 = t.back.size() / P.maxleaves;
+      for (size_t i = 0; i < sc2; ++i) {
         if (t.delta[i] == 0xFFFF) continue;
-        if (t.delta[i] >= P.nstates || t.act[i] >= P.nactions || t.pback[i] >= P.nback) bad("transition out of range");
+        if (t.delta[i] >= P.nstates || t.act[i] >= t.actions.size() || t.pback[i] >= nback2) bad("transition out of range");
       }
       for (uint32_t q = 0; q < P.nstates; ++q) {
         if (t.final_act[q] != 0xFFFFFFFFu && t.final_act[q] >= P.nactions) bad("final action out of range");
@@ -254,8 +346,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
         if ((t.final_act[q] == 0xFFFFFFFFu) != (P.final_leaf[q] == 0xFF)) bad("final action and final leaf disagree");
       }
       t.nleaves.assign(P.nleaves, P.nleaves + P.nstates); t.fin_leaf.assign(P.final_leaf, P.final_leaf + P.nstates);
-      t.back.assign(P.back, P.back + (size_t)P.nback * P.maxleaves);
-      for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= P.npconsts)) bad("backward entry out of range");
+      for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= t.pconsts.size())) bad("backward entry out of range");
       t.init_const.assign(P.init_const, P.init_const + P.maxleaves);
       for (uint32_t v : t.init_const) if (v >= P.npconsts) bad("initial constant out of range");
       if (P.action_regs > 250) bad("too many action registers");

@@ -241,7 +241,8 @@ class KexcIlProgram(ctypes.Structure):
                 ("maxleaves", ctypes.c_uint32), ("nback", ctypes.c_uint32), ("back_row", _u32p),
                 ("nleaves", _u8p), ("final_leaf", _u8p), ("back", _u32p),
                 ("npconsts", ctypes.c_uint32), ("pconst_off", _u32p), ("pconst_pool", _u8p), ("init_const", _u32p),
-                ("has_actions", ctypes.c_uint32), ("action_regs", ctypes.c_uint32)]
+                ("has_actions", ctypes.c_uint32), ("action_regs", ctypes.c_uint32),
+                ("ntables", ctypes.c_uint32), ("tbl_width", _u32p), ("tbl_data", _u8p), ("back_table", _u32p)]
 
 
 class KexcPipeline(ctypes.Structure):
@@ -262,6 +263,11 @@ def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bi
         for k in ("nstates", "nclasses", "init_state", "nregs", "nactions", "nconsts", "maxleaves", "nback", "npconsts"):
             setattr(st, k, int(P[k]))
         st.has_actions, st.action_regs = int(P.get("has_actions", 0)), int(P.get("action_regs", 0))
+        st.ntables = int(P.get("ntables", 0))
+        for k, dt in (("tbl_width", np.uint32), ("tbl_data", np.uint8), ("back_table", np.uint32)) if st.ntables else ():
+            a = np.ascontiguousarray(np.asarray(P[k], dtype=dt).ravel())
+            keep.append(a)
+            setattr(st, k, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8 if dt == np.uint8 else ctypes.c_uint32)))
         for k, dt in kinds.items():
             a = np.ascontiguousarray(np.asarray(P[k], dtype=dt).ravel())
             if a.size == 0:

@@ -93,3 +93,48 @@ def test_multi_stage_and_argument_errors(tmp_path):
     bad = flip_ab_program(); bad["delta"] = [0, 7, 0, 0xFFFF]
     with pytest.raises(CompileError, match="out of range"):
         emit_pipeline([bad], srcout=out)
+
+
+def coder_program_with_table():
+    """The coder of `[a-d]*` the way the reference's compileCoder hands it over (Commands.hs:246-275): the class [a-d] has
+    more than one member, so its symbol code is an `AppendTblI` (IL.hs:44; table built by SSTCompiler/Classes.hs:102-125),
+    not a constant.  One block: on [a-d] append 00 (star: loop) and table[sym]; at end of input append 01 (star: leave).
+    Path tree of the block: leaf 0 waits for a symbol (its pending choice 00), leaf 1 stands in the final state (01)."""
+    cls = np.full(256, 1, dtype=np.uint8)
+    cls[ord("a"):ord("d") + 1] = 0
+    table = np.zeros(256, dtype=np.uint8)
+    table[ord("a"):ord("d") + 1] = [0, 1, 2, 3]
+    none = 0xFFFFFFFF
+    return dict(
+        nstates=1, nclasses=2, init_state=0, nregs=1, class_of=cls,
+        delta=[0, 0xFFFF], action=[0, 0], final_action=[1],
+        nactions=2, action_off=[0, 2, 3], ops=[(1 << 24) | 0, 0, (4 << 24) | 0, 0, (1 << 24) | 0, 1],
+        nconsts=2, const_off=[0, 1, 2], const_pool=[0, 1],
+        maxleaves=2, nback=1, back_row=[0, 0], nleaves=[2], final_leaf=[1],
+        back=[0 | (0 << 8) | (0 << 9), 0 | (0 << 8) | (1 << 9)], back_table=[0, 0],
+        npconsts=2, pconst_off=[0, 1, 2], pconst_pool=[0, 1], init_const=[0, 1],
+        ntables=1, tbl_width=[1], tbl_data=table)
+
+
+def test_append_table_instruction_is_lowered_to_constants_per_refined_class(tmp_path):
+    """AppendTblI at the seam: classes are refined until the table is constant on each (a, b, c, d, the rest), the table
+    entries become constants, and the result is the program `kexc compile --re '[a-d]*'` builds itself."""
+    from kleenexlang_amd import host
+    out = tmp_path / "coder.kxp"
+    assert emit_pipeline([coder_program_with_table()], srcout=out) == 0
+    blob = out.read_bytes()
+    st = kxp.parse(blob)[0]
+    assert st.nclasses == 5 and len(set(int(st.cls[c]) for c in b"abcd")) == 4
+    own = host.compile_regex("[a-d]*")
+    for data in (b"", b"a", b"abcd", b"ddcbaabcd" * 50):
+        want = bytes(x for ch in data for x in (0, ch - ord("a"))) + b"\x01"
+        for pf in (False, True):
+            assert oracle.run(blob, data, path_form=pf) == want == oracle.run(own, data, path_form=pf), (data, pf)
+    with pytest.raises(oracle.OracleMatchError):
+        oracle.run(blob, b"abe")
+    bad = coder_program_with_table(); bad["ops"] = [(1 << 24) | 0, 0, (4 << 24) | 0, 3, (1 << 24) | 0, 1]
+    with pytest.raises(CompileError, match="malformed micro-op"):
+        emit_pipeline([bad], srcout=out)
+    bad = coder_program_with_table(); bad["final_action"] = [0]
+    with pytest.raises(CompileError, match="final action"):
+        emit_pipeline([bad], srcout=out)

@@ -328,3 +328,29 @@ def test_coder_binary_and_simulate(tmp_path):
     assert r.returncode == 1 and b"Match error at input symbol 4!" in r.stderr, r.stderr
     r = subprocess.run([str(binp), "-i"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert b"Oracle SST states" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_random_regex_coders_on_the_engine():
+    """Soak: random regexes (the generator of the CPU test) × strings drawn from their own language by a random walk over
+    the model, blown up to KiB sizes by repetition under an outer star — engine against the CPU oracle, every byte."""
+    rnd = random.Random(4242)
+    runs = 0
+    for _ in range(40):
+        inner = _random_regex(rnd)
+        regex = "((" + inner + ")x)*"
+        blob = host.compile_regex(regex, opt=rnd.choice([0, 3]))
+        words = []
+        for _ in range(200):
+            w = bytes(rnd.choice(b"abc") for _ in range(rnd.randrange(0, 6)))
+            if greedy_code(inner, w) is not None:
+                words.append(w)
+        if not words:
+            continue
+        prog = host.Program(blob, segment_bytes=rnd.choice([0, 4096, 16384]))
+        for size in (0, 1, 50, 3000, 40000):
+            data = b"".join(rnd.choice(words) + b"x" for _ in range(size))
+            assert prog.run_host(data) == oracle.run(blob, data), (regex, size)
+            runs += 1
+        prog.close()
+    assert runs >= 100

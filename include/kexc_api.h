@@ -68,8 +68,11 @@ typedef struct kexc_il_program {
 } kexc_il_program;
 
 /* `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per
- * program; Right = (oracle, action) pairs, programs[2i] and programs[2i+1] — accepted by the type, refused by this
- * build (register actions are not executed on the device yet). */
+ * program; Right = (oracle, action) pairs, programs[2i] and programs[2i+1] — accepted by the type, refused: the action
+ * program (actionToSST, src/KMC/SymbolicSST/ActionSST.hs:47-104) is a register machine whose registers hold data (the
+ * contents of `r@t`), not the pending output of undecided paths, so it has no path form.  Register actions reach the
+ * engine the other way: ONE program per stage whose output carries the actions in band (has_actions below) and the
+ * action post-pass on the device (`kexc_compile` does this for Kleenex source). */
 typedef struct kexc_pipeline { int is_oracle_action; uint32_t nprograms; const kexc_il_program* programs; } kexc_pipeline;
 
 /* compileProgram (src/KMC/Program/Backends/C.hs:529-540), argument for argument:

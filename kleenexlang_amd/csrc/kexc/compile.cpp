@@ -211,7 +211,9 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
     using namespace kexc;
     if (!pl || !pl->programs || pl->nprograms == 0) throw CompileError("empty pipeline");
     if (buffer_unit_bits != 8) throw CompileError("buffer unit must be 8 bits (UInt8T): the engine's output is a byte stream (--wordsize 8)");
-    if (pl->is_oracle_action) throw CompileError("oracle/action pipelines (Right [(Program, Program)]) are not executable yet: compile with --act=false");
+    if (pl->is_oracle_action) throw CompileError("oracle/action pipelines (Right [(Program, Program)]) are not taken: the action program's registers hold data (ActionSST.hs:47-104), "
+                                                    "not path choices, so it has no path form; hand over the transducer with its actions in band instead (has_actions, kxp_format.h) "
+                                                    "or compile with --act=false");
     std::vector<StageTables> stages;
     for (uint32_t pi = 0; pi < pl->nprograms; ++pi) {
       const kexc_il_program& P = pl->programs[pi];

@@ -244,6 +244,32 @@ def test_produced_binary_stdin_stdout_contract(tmp_path):
     assert r.returncode == 1 and r.stdout == b"" and r.stderr.endswith(b"Match error at input symbol 1000!\n")
 
 
+def test_produced_binary_writes_regular_files_in_place(tmp_path):
+    """`BIN < in > out` on regular files (input read with positioned parallel reads, output written in order): output lands
+    after whatever the descriptor already stood behind (`> out` opened by a shell that wrote a header first), is appended
+    in `>>` mode, and the descriptor's position ends behind it."""
+    import subprocess
+    from kleenexlang_amd import build, program_path
+    exe = tmp_path / "apache"
+    assert subprocess.run([os.path.join(build.OUT, "kexc"), "compile", "--quiet", program_path("apache_log"), "--out", str(exe)]).returncode == 0
+    data = workloads.generate("apache_log", 9 << 20, 77)
+    want = oracle.run(blob_of("apache_log"), data)
+    src = tmp_path / "in.log"
+    src.write_bytes(data)
+    for env in ({}, {"KX_WINDOW_BYTES": str(1 << 20), "KX_READ_THREADS": "3"}):
+        e = {**os.environ, **env}
+        out = tmp_path / "out.json"
+        with open(src, "rb") as fi, open(out, "wb") as fo:
+            fo.write(b"HEADER\n"); fo.flush()
+            assert subprocess.run([str(exe)], stdin=fi, stdout=fo, env=e).returncode == 0
+            assert os.lseek(fo.fileno(), 0, os.SEEK_CUR) == 7 + len(want)
+            os.write(fo.fileno(), b"TRAILER\n")
+        assert out.read_bytes() == b"HEADER\n" + want + b"TRAILER\n"
+        with open(src, "rb") as fi, open(out, "ab") as fo:
+            assert subprocess.run([str(exe)], stdin=fi, stdout=fo, env=e).returncode == 0
+        assert out.read_bytes() == b"HEADER\n" + want + b"TRAILER\n" + want
+
+
 def test_produced_binary_streams_inputs_in_windows(tmp_path):
     """kx_run_fd keeps a bounded window of the input in HBM: every window is one shard of the sharded
     protocol (start state from the previous window, end leaf from the next).  Windows far smaller than the

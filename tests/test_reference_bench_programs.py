@@ -107,3 +107,28 @@ def test_make_danish_register_form_and_path_form_agree():
     text = data + b" computer debugger e-mail free software pull request web site damn it Pawel"
     assert oracle.run(blob, text, path_form=True) == oracle.run(blob, text, path_form=False)
     assert b"datamat afluser elektropost fri software haleanmodning spindel site" in oracle.run(blob, text)
+
+
+def test_reference_regex_sources_compile_as_coders_and_routes_agree():
+    """bench/regex_src/*.rx — the reference's two regex-flavour sources (`kexc compile FILE.rx` builds their bit-coder,
+    kexc.hs:46-48).  No expected outputs exist for them in the reference; the routes must agree on strings of their
+    languages: lock-step simulation of the oracle machine, register form, path form."""
+    files = sorted(glob.glob(os.path.join(REF, "bench", "regex_src", "*.rx")))
+    assert len(files) >= 2
+    for f in files:
+        regex = open(f, encoding="utf-8").read()
+        blob = host.compile_regex(regex, name=f)
+        host.validate_blob(blob)
+        fst = host.dump_regex_fst(regex, oracle=True)
+        name = os.path.basename(f)
+        inputs = [b"", b"a", b"aaaaaaa"] if name == "as.rx" else [b"aaf1,f2,,f4,f5,f6\n", b",,,,,\n", b"x,y\n", b"a,b,c,d,e,f,g\n"]
+        accepted = 0
+        for data in inputs:
+            want = fst_sim.run(fst, data)
+            if want is None:
+                with pytest.raises(oracle.OracleMatchError):
+                    oracle.run(blob, data)
+            else:
+                accepted += 1
+                assert oracle.run(blob, data) == oracle.run(blob, data, path_form=True) == want, (name, data)
+        assert accepted >= 2, name

@@ -31,7 +31,7 @@ for name, (src, line) in PROGRAMS.items():
     data = base * max(1, (16 << 20) // len(base))
     blob = host.compile_source(src)
     want = oracle.run(blob, data)
-    prog = host.Program(blob)
+    prog = host.Program(blob, collect_timing=True)
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     out = torch.empty(len(want) + (1 << 20), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -42,6 +42,7 @@ for name, (src, line) in PROGRAMS.items():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = olen == len(want) and bytes(out[:olen].cpu().numpy().tobytes()) == want
-    res[name] = {"input_bytes": len(data), "output_bytes": olen, "seconds": round(dt, 4), "input_MBps": round(len(data) / dt / 1e6, 1), "bit_exact": ok}
+    km = prog.last_stats.as_dict()
+    res[name] = {"transducer_kernels_ms": round(sum(km["kernel_ms"].values()), 2), "unsynced_segments": km.get("unsynced_segments"), "input_bytes": len(data), "output_bytes": olen, "seconds": round(dt, 4), "input_MBps": round(len(data) / dt / 1e6, 1), "bit_exact": ok}
     prog.close()
 print(json.dumps(res))

@@ -6,7 +6,7 @@ import random
 import pytest
 from conftest import GOLDEN, blob_of, dictionary_program, line_expected, line_input, same_modulo_trailing_newlines
 
-from kleenexlang_amd import MatchError, Program, workloads
+from kleenexlang_amd import MatchError, Program, compile_source, workloads
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -583,3 +583,28 @@ def test_kexc_simulate_runs_the_program_on_the_engine(tmp_path):
     eof.write_text('main := /a/ /b/\n')
     r = subprocess.run([kexc, "simulate", "--sim", "sst", str(eof)], input=b"a", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 1 and r.stderr.endswith(b"End of input reached, but final state is not accepting.\n"), r.stderr
+
+
+@pytest.mark.gpu
+def test_action_mirrors_in_lds_fall_back_to_global_memory():
+    """k_actions mirrors the top of the frame stack and small registers in LDS (16 KiB each).  Frames and registers that
+    outgrow the mirrors, registers written long after they were popped (the register arena has been reset in between),
+    deep nesting and many registers must all give the oracle's bytes."""
+    rnd = random.Random(99)
+    cases = []
+    # one frame far larger than the mirror, then written twice (the second write finds it empty)
+    cases.append(('main := big@/[a-z]*/ ~/;/ "<" !big "|" !big ">"\n', [b"abc;", bytes(rnd.choice(b"abcdefgh") for _ in range(70000)) + b";"]))
+    # 26 registers filled one after the other with lines of 0..3000 bytes (the register arena wraps), written in reverse order
+    regs = "abcdefghijklmnopqrstuvwxyz"
+    src = "main := " + " ".join("r%s@line" % c for c in regs) + " " + " ".join("!r%s" % c for c in reversed(regs)) + "\nline := /[^\\n]*/ ~/\\n/\n"
+    lines = [bytes(rnd.choice(b"0123456789") for _ in range(rnd.choice([0, 1, 17, 900, 3000]))) for _ in regs]
+    cases.append((src, [b"".join(l + b"\n" for l in lines)]))
+    # nesting: inner registers popped inside an outer frame that keeps growing past the mirror
+    cases.append(('main := o@(item*) "[" !o "]"\nitem := i@/[a-z]+/ ~/,/ "(" !i ")"\n',
+                  [b"ab,c,", b"".join(bytes(rnd.choice(b"xyz") for _ in range(rnd.randrange(1, 400))) + b"," for _ in range(400))]))
+    for src, inputs in cases:
+        blob = compile_source(src)
+        prog = Program(blob)
+        for data in inputs:
+            assert prog.run_host(data) == oracle.run(blob, data), (src[:40], len(data))
+        prog.close()

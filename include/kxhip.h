@@ -66,7 +66,9 @@ typedef struct kx_config {
   uint32_t block_threads;  /* workgroup size (power of two); default 512        */
   uint32_t collect_timing; /* record per-kernel HIP events into kx_stats        */
   uint32_t phase;          /* kx_run_fd: 0 = the whole pipeline; K = only phase K, stdin -> stdout (`BIN --phase K`, crt/crt.c:390-393,408-411) */
-  uint64_t window_bytes;   /* kx_run_fd: input bytes resident at a time; 0 = 4 GiB (env KX_WINDOW_BYTES overrides) */
+  uint64_t window_bytes;   /* kx_run_fd: input bytes resident at a time; 0 = 1 GiB (env KX_WINDOW_BYTES overrides;
+                              KX_READ_THREADS = pread threads per chunk of a regular file, default 4; KX_FD_TRACE=1 prints where
+                              the reader / compute / writer threads spent their time) */
 } kx_config;
 
 int kx_load(const void* blob, size_t blob_len, kx_program** prog);

@@ -25,7 +25,7 @@ for f in glob.glob("/tmp/pmc_*.csv"):
     for k, (n, v) in acc.items():
         res[k][c] = v / n
 json.dump({"workload": "apache_log 2 GiB, per launch (device totals)", "kernels": res}, open(out + "/sq_counters.json", "w"), indent=1)
-for k in [x for x in ("k_emit2", "k_emit", "k_backlen", "k_forward") if x in res]:
+for k in [x for x in ("k_place", "k_emit", "k_backlen", "k_forward") if x in res]:
     d = res[k]
     print(k, "LDS active / CU-cycles = %.2f" % (d["SQ_LDS_IDX_ACTIVE"] / 256 / (d["GRBM_GUI_ACTIVE"] / 8)),
           "conflict share = %.2f" % (d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]),

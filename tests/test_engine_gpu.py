@@ -477,30 +477,6 @@ def test_register_actions_on_the_engine(tmp_path):
     p.close()
 
 
-def test_run_trace_pipeline_matches(monkeypatch):
-    """the run-trace pipeline of round 2 (k_forward2 → k_backlen2/k_fixtail2 → k_emit2; `KX_SPARSE=1`) stays
-    bit-exact while it waits for a cheaper record producer — workloads, ragged sizes, failure positions, small segments."""
-    monkeypatch.setenv("KX_SPARSE", "1")
-    for prog in ("apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"):
-        blob = blob_of(prog)
-        for seg in (64, 4096, 0):
-            for n, seed in [(3000, 21), (700000, 22)]:
-                data = workloads.generate(workloads.PROGRAM_INPUT[prog], n, seed)
-                got, want = both(blob, data, segment_bytes=seg)
-                assert got == want, (prog, seg, n)
-    blob = blob_of("apache_log")
-    data = workloads.generate("apache_log", 400000, 23)
-    cut = data.index(b"\n", 250000) + 1
-    for bad in (data[:cut] + b"\n" + data[cut:], data[:cut + 17]):     # an empty line mid-input; input ending inside a line
-        got, want = both(blob, bad, segment_bytes=4096)
-        assert got == want and got[0] == "fail"
-    # the dense kernels with the break-record output stage (k_brkref + k_emit2)
-    monkeypatch.delenv("KX_SPARSE")
-    monkeypatch.setenv("KX_EMIT2", "1")
-    got, want = both(blob, data, segment_bytes=4096)
-    assert got == want
-
-
 def test_tables_beyond_16_bit_addressing_run_from_global_memory(monkeypatch):
     """a program whose image exceeds 64 KiB (make_danish-sized: ~1000 states x 28 classes) is not
     refused any more — its GENERAL kernel instances read the image from global memory with scaled handles

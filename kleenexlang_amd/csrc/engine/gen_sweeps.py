@@ -168,36 +168,18 @@ def fwd1(pack):
     return L
 
 
-def walk1(info=False):
-    """backward walk that only measures: leaf chain + appended-byte sum.  info=False: also the state in the middle of the
-    piece (k_emit's second chain starts there).  info=True: the KIND byte of every step (byte 2 of its entry) is gathered,
-    one byte per input symbol in input order — what k_place needs to know about the piece — and every finished dword is
-    stored into the lane's 64-byte LDS slot (the store rides behind the next step's entry read: LDS operations return in
-    order, so waiting for all but one waits for the read only)."""
+def walk1():
+    """backward walk that only measures: leaf chain + appended-byte sum, with the state in the middle of the piece"""
     L = []
     ap = L.append
     ap("s_setprio 2")
-    pend = None   # info dword finished by the previous step, still to be stored
     for t in range(63, -1, -1):
         ap("v_add_u32_sdwa %%[a], %%[bo%d], %%[leaf] %s src0_sel:WORD_%d src1_sel:DWORD" % (t >> 1, SD, t & 1))
         ap("ds_read_b32 %[e], %[a]")
-        if pend is not None:
-            ap("ds_write_b32 %%[slot], %%[i%d] offset:%d" % (pend & 1, 4 * pend))
-        ap("s_waitcnt lgkmcnt(%d)" % (1 if pend is not None else 0))
-        pend = None
+        ap("s_waitcnt lgkmcnt(0)")
         ap("v_and_b32 %[leaf], 0x3fc, %[e]")
         ap("v_add_u32_sdwa %%[sum], %%[sum], %%[e] %s src0_sel:DWORD src1_sel:BYTE_3" % SD)
-        if info:
-            d = t >> 2
-            if t & 3 == 3:   # first step of its dword: byte 2 -> byte 3 (the three lower bytes are overwritten by the next steps)
-                ap("v_lshlrev_b32 %%[i%d], 8, %%[e]" % (d & 1))
-            else:
-                ap("v_mov_b32_sdwa %%[i%d], %%[e] dst_sel:BYTE_%d dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" % (d & 1, t & 3))
-            if t & 3 == 0:
-                pend = d
-                if t == 0:
-                    ap("ds_write_b32 %%[slot], %%[i%d] offset:%d" % (d & 1, 4 * d))
-        elif t == 32:
+        if t == 32:
             ap("v_mov_b32 %[lmid], %[leaf]")
             ap("v_mov_b32 %[shi], %[sum]")
     ap("s_setprio 0")
@@ -315,13 +297,6 @@ def main2(out):
             walk1(),
             ['[a] "=&v"(a)', '[e] "=&v"(e)', '[lmid] "=&v"(lmid)', '[shi] "=&v"(shi)', '[leaf] "+v"(leaf)', '[sum] "+v"(sum)'],
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)],
-            '"memory"')
-    emit_fn(out, "piece_walk1i",
-            "const uint32_t (&bo)[32], uint32_t& leaf, uint32_t& sum, uint32_t slot",
-            "uint32_t a, e, i0, i1;",
-            walk1(True),
-            ['[a] "=&v"(a)', '[e] "=&v"(e)', '[i0] "=&v"(i0)', '[i1] "=&v"(i1)', '[leaf] "+v"(leaf)', '[sum] "+v"(sum)'],
-            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[slot] "v"(slot)'],
             '"memory"')
 
 

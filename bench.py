@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the sharded protocol even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the boundary hand-off")
     ap.add_argument("--single-device", action="store_true", help="(validation) put every rank on cuda:0")
+    ap.add_argument("--py-driver", action="store_true", help="boundary hand-off driven from Python over torch.distributed (kleenexlang_amd/sharded.py) "
+                                                               "instead of the library's own driver (kx_run_sharded + RCCL communicator)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -107,6 +109,10 @@ def main():
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_IB_DISABLE", "1")
         import torch.distributed as dist
+        # (RCCL prints a version banner on stdout when a communicator comes up; stdout must carry the one JSON line only)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if a.backend == "nccl":
@@ -143,11 +149,32 @@ def main():
     out = torch.empty(int(n_local * expansion) + (1 << 20), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    totals = {"out": None, "off": 0}
+    totals = {"out": None, "off": 0, "boundary_ms": 0.0}
+    comm = None
+    if use_dist and not a.py_driver:
+        # the library's own communicator: rank 0 makes the id, torch.distributed only carries it to the other ranks
+        from kleenexlang_amd.host import Comm
+        ids = [Comm.unique_id() if rank == 0 and world > 1 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        comm = Comm(rank, world, ids[0])
+    if use_dist:
+        dist.barrier()   # (bring the communicators up before stdout is given back)
+        sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # (the banner sits in C stdio's buffer)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     def step():
         if not use_dist:
             return prog.run_device(t.data_ptr(), n_local, out.data_ptr(), out.numel(), stream)
+        if comm is not None:   # kx_run_sharded: every stage, the hand-off inside the library
+            res = prog.run_sharded(rank, world, comm, t.data_ptr(), n_local, out.data_ptr(), out.numel(), stream)
+            prog.last_stats = res.stats
+            totals["out"], totals["off"] = int(res.total_out), int(res.out_offset)
+            totals["boundary_ms"] += float(res.boundary_ms)
+            return int(res.out_len)
         sh = prog.shard_begin(0, t.data_ptr(), n_local, rank == 0, rank == world - 1, stream)
         res = sharded.raise_on_fail(sharded.run_stage_dist(sh, n_local, comm_dev))
         sh.emit(out.data_ptr(), out.numel())
@@ -165,6 +192,7 @@ def main():
         step()
     fence()
     kern = {}
+    totals["boundary_ms"] = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         olen = step()
@@ -227,6 +255,8 @@ def main():
                        "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "output_bytes_total": total_out,
                        "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
                        "parallelism": "shard%d" % world, "boundary_backend": (a.backend if use_dist else None),
+                       "boundary_driver": (None if not use_dist else "python (sharded.py over torch.distributed)" if a.py_driver else "kx_run_sharded (C, own RCCL communicator)"),
+                       "boundary_ms_per_step_rank0": (round(totals["boundary_ms"] / a.steps, 4) if comm is not None else None),
                        "single_device_validation": bool(a.single_device)},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_note,

@@ -129,6 +129,46 @@ int kx_shard_emit(kx_shard* s, void* d_out, size_t cap);
 void kx_shard_stats(kx_shard* s, kx_stats* stats);
 void kx_shard_end(kx_shard* s);
 
+/* ---- the multi-GPU driver: the protocol above, run by the library itself ---------------------------------------
+ * One rank per GPU (a process, or a thread of one process); rank r holds shard r of the input on its own current device.
+ * kx_run_sharded runs every pipeline stage over the rank's shard and takes part in the boundary hand-off — four
+ * all-gathers of fixed-size records per stage (40, 40, 272 and 8 bytes per rank), nothing else crosses ranks — through
+ * the all-gather it is given:
+ *   kx_comm_*   RCCL: `ncclAllGather` on the communicator's own pinned buffers and stream (xGMI between the GPUs of a node;
+ *               librccl is dlopen'ed).  Rank 0 makes the 128-byte id (kx_comm_unique_id) and the launcher hands it to every
+ *               rank (ncclGetUniqueId / ncclCommInitRank's contract); every rank then calls kx_comm_init on its device.
+ *   kx_group_*  the threads of one process (the produced binary's `--gpus N`): exchange through host memory.
+ * With world = 1 no exchange takes place (ag may be NULL).  Returns as kx_run_device: 0, 1 (match error: res->stats.fail_pos
+ * is the GLOBAL position, the same on every rank), or < 0 (KX_E_CAPACITY: res->out_len = bytes this rank needs).
+ * The rank's output slice [out_offset, out_offset + out_len) of the total_out output bytes stays on its device. */
+typedef int (*kx_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes);   /* recv holds world * bytes; 0 = ok */
+typedef struct kx_sharded_result {
+  uint64_t out_len, out_offset, total_out;
+  float boundary_ms;   /* wall time this rank spent inside the all-gathers (waiting for the slowest rank included) */
+  kx_stats stats;      /* kernel times summed over the stages; fail_pos / fail_stage on a match error */
+} kx_sharded_result;
+int kx_run_sharded(kx_program* prog, int rank, int world, kx_allgather_fn ag, void* ag_ctx, const void* d_in, size_t n,
+                   void* d_out, size_t cap, kx_sharded_result* res, void* stream);
+
+/* The produced binary's `--gpus N`: stdin must be a regular file; it is cut into N contiguous shards (4 KiB multiples), one
+ * thread and one program instance per GPU, hand-off through host memory (kx_group_*); the output is written at each rank's
+ * offset (regular file) or in rank order (pipe).  Same return codes and match-error position as kx_run_fd. */
+int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, int out_fd, kx_stats* stats);
+
+typedef struct kx_comm kx_comm;
+int kx_comm_unique_id(void* id128);
+int kx_comm_init(kx_comm** comm, int rank, int world, const void* id128);
+void kx_comm_free(kx_comm* comm);
+int kx_comm_allgather(void* comm, const void* send, void* recv, size_t bytes);            /* a kx_allgather_fn */
+
+typedef struct kx_group kx_group;
+typedef struct kx_group_member kx_group_member;
+kx_group* kx_group_create(int world);
+void kx_group_free(kx_group* g);
+kx_group_member* kx_group_join(kx_group* g, int rank);
+void kx_group_leave(kx_group_member* m);
+int kx_group_allgather(void* member, const void* send, void* recv, size_t bytes);         /* a kx_allgather_fn */
+
 #ifdef __cplusplus
 }
 #endif

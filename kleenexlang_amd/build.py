@@ -67,7 +67,8 @@ def build_engine(force=False):
         if not os.path.exists(HIPCC):
             raise RuntimeError("hipcc not found at %s" % HIPCC)
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-              "-Wall", "-Wno-unused-result", "-o", lib, os.path.join(CSRC, "engine", "kx_engine.hip")])
+              "-Wall", "-Wno-unused-result", "-o", lib, os.path.join(CSRC, "engine", "kx_engine.hip"),
+              os.path.join(CSRC, "engine", "kx_sharded.cpp"), "-ldl", "-lpthread"])
     drv = os.path.join(OUT, "kxrun")
     if force or _newer(drv, deps):
         _run(["g++", "-O2", "-std=c++17", "-o", drv, os.path.join(CSRC, "engine", "kxrun.cpp"), "-ldl"])
@@ -81,7 +82,7 @@ def engine_sha():
     h = hashlib.sha256()
     d = os.path.join(CSRC, "engine")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".inc", ".py", ".h")):     # (the kernels and what generates them; not kxrun.cpp, the host driver)
+        if name.endswith((".hip", ".inc", ".py", ".h")):     # (the kernels and what generates them; not kxrun.cpp / kx_sharded.cpp, host code)
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     with open(os.path.join(ROOT, "include", "kxp_format.h"), "rb") as f:

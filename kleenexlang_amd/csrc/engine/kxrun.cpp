@@ -7,7 +7,8 @@
 // stderr and exits 1.  `-p/--phase K` runs only phase K, stdin to stdout, as in
 // the reference (crt.c:390-393,408-411); without it the phases of a pipeline run
 // as chained device-resident stages inside one process (instead of
-// fork()+pipe(), crt.c:414-454).
+// fork()+pipe(), crt.c:414-454).  `--gpus N` (no counterpart in the reference) shards a regular
+// file on stdin over N GPUs (kx_run_fd_sharded).
 //
 // BIN = this executable ++ KXP blob ++ libdir ++ trailer (see kexc main.cpp).
 // The engine is loaded with dlopen so that this file carries no HIP dependency.
@@ -52,9 +53,9 @@ int main(int argc, char** argv) {
   if (fread(blob.data(), 1, bl, self) != bl || fread(&libdir[0], 1, dl, self) != dl) { fprintf(stderr, "corrupt payload\n"); return 1; }
   fclose(self);
 
-  static struct option long_options[] = {{"phase", required_argument, 0, 'p'}, {0, 0, 0, 0}};
+  static struct option long_options[] = {{"phase", required_argument, 0, 'p'}, {"gpus", required_argument, 0, 'g'}, {0, 0, 0, 0}};
   bool timing = false;
-  long phase = 0;
+  long phase = 0, gpus = 0;
   int c;
   while ((c = getopt_long(argc, argv, "ihtp:", long_options, nullptr)) != -1) {
     switch (c) {
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
         return 2;
       }
       case 't': timing = true; break;
+      case 'g': gpus = atol(optarg); if (gpus < 1 || gpus > 64) { fprintf(stderr, "Invalid number of GPUs: %ld given\n", gpus); return 1; } break;
       case 'p': phase = atol(optarg); if (phase < 1) { fprintf(stderr, "Invalid phase: %ld given\n", phase); return 1; } break;
       case 'h':
       default: usage(argv[0]); return 1;
@@ -83,6 +85,13 @@ int main(int argc, char** argv) {
   auto run = (int (*)(kx_program*, int, int, kx_stats*))dlsym(h, "kx_run_fd");
   auto lasterr = (const char* (*)(void))dlsym(h, "kx_last_error");
   if (!load || !run || !lasterr) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
+  kx_stats st;
+  int rc;
+  if (gpus) {
+    auto runs = (int (*)(const void*, size_t, int, int, int, kx_stats*))dlsym(h, "kx_run_fd_sharded");
+    if (!runs || phase) { fprintf(stderr, "%s: --gpus cannot be combined with --phase\n", argv[0]); return 1; }
+    rc = runs(blob.data(), blob.size(), (int)gpus, STDIN_FILENO, STDOUT_FILENO, &st);
+  } else {
   kx_program* prog = nullptr;
   if (load(blob.data(), blob.size(), &prog)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
   if (phase) {
@@ -94,8 +103,8 @@ int main(int argc, char** argv) {
     cfg.phase = (uint32_t)phase;
     if (setcfg(prog, &cfg)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
   }
-  kx_stats st;
-  int rc = run(prog, STDIN_FILENO, STDOUT_FILENO, &st);
+  rc = run(prog, STDIN_FILENO, STDOUT_FILENO, &st);
+  }
   if (rc == KX_MATCH_ERROR) {
     // `kexc simulate` runs its program through this driver and wants the reference simulators' words instead of the
     // compiled binary's (Commands.hs:285,298 "Reject"; SymbolicSST.hs:425,427)

@@ -53,6 +53,14 @@ class KxStats(ctypes.Structure):
                 "kernel_ms": {k: self.kernel_ms[i] for i, k in enumerate(KERNEL_NAMES)}}
 
 
+class KxShardedResult(ctypes.Structure):
+    _fields_ = [("out_len", ctypes.c_uint64), ("out_offset", ctypes.c_uint64), ("total_out", ctypes.c_uint64),
+                ("boundary_ms", ctypes.c_float), ("stats", KxStats)]
+
+
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
 class KxConfig(ctypes.Structure):
     _fields_ = [("segment_bytes", ctypes.c_uint32), ("block_threads", ctypes.c_uint32),
                 ("collect_timing", ctypes.c_uint32), ("phase", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
@@ -132,6 +140,16 @@ def load_engine():
         lib.kx_shard_emit.argtypes = [vp, vp, sz]
         lib.kx_shard_stats.argtypes = [vp, ctypes.POINTER(KxStats)]
         lib.kx_shard_end.argtypes = [vp]
+        lib.kx_run_sharded.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, sz, vp, sz, ctypes.POINTER(KxShardedResult), vp]
+        lib.kx_comm_unique_id.argtypes = [ctypes.c_char_p]
+        lib.kx_comm_init.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+        lib.kx_comm_free.argtypes = [vp]
+        lib.kx_group_create.argtypes = [ctypes.c_int]
+        lib.kx_group_create.restype = vp
+        lib.kx_group_free.argtypes = [vp]
+        lib.kx_group_join.argtypes = [vp, ctypes.c_int]
+        lib.kx_group_join.restype = vp
+        lib.kx_group_leave.argtypes = [vp]
         _kxhip = lib
     return _kxhip
 
@@ -398,11 +416,82 @@ class Program:
     def stage_has_actions(self, stage):
         return bool(self._lib.kx_stage_has_actions(self._h, stage))
 
+    def run_sharded(self, rank, world, gather, d_in, n, d_out, cap, stream=None):
+        """kx_run_sharded: this rank's shard through every stage, the boundary hand-off done by the library through `gather`
+        (a Comm, a GroupMember, or None when world == 1).  Returns the KxShardedResult; raises MatchError (global position)."""
+        res = KxShardedResult()
+        fn, ctx = (None, None) if gather is None else gather.callback()
+        rc = self._lib.kx_run_sharded(self._h, rank, world, fn, ctx, ctypes.c_void_p(d_in), n, ctypes.c_void_p(d_out), cap,
+                                      ctypes.byref(res), ctypes.c_void_p(stream or 0))
+        if rc == -3:
+            self.last_stats = res.stats
+            raise EngineError("output buffer too small: need %d bytes" % res.out_len)
+        self._check(rc, res.stats)
+        return res
+
     def shard_begin(self, stage, d_in, n, is_first, is_last, stream=None):
         if self.stage_has_actions(stage):
             raise EngineError("stage %d uses register actions: their replay is sequential over the whole stream, "
                               "run the program unsharded (kx_run_device / kx_run_fd)" % stage)
         return Shard(self, stage, d_in, n, is_first, is_last, stream)
+
+
+class Comm:
+    """The library's own RCCL communicator (kx_comm_*): rank 0 makes the 128-byte id, the launcher distributes it."""
+
+    def __init__(self, rank, world, unique_id=None):
+        self._lib = load_engine()
+        self._h = ctypes.c_void_p()
+        rc = self._lib.kx_comm_init(ctypes.byref(self._h), rank, world, unique_id)
+        if rc:
+            raise EngineError(self._lib.kx_last_error().decode("utf-8", "replace"))
+
+    @staticmethod
+    def unique_id():
+        lib = load_engine()
+        buf = ctypes.create_string_buffer(128)
+        if lib.kx_comm_unique_id(buf):
+            raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+        return buf.raw
+
+    def callback(self):
+        return ctypes.cast(self._lib.kx_comm_allgather, ctypes.c_void_p), self._h
+
+    def close(self):
+        if self._h:
+            self._lib.kx_comm_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class Group:
+    """Ranks = threads of this process (kx_group_*): what the produced binary's `--gpus N` uses."""
+
+    def __init__(self, world):
+        self._lib = load_engine()
+        self._h = ctypes.c_void_p(self._lib.kx_group_create(world))
+        self.world = world
+
+    def member(self, rank):
+        return GroupMember(self, rank)
+
+    def close(self):
+        if self._h:
+            self._lib.kx_group_free(self._h)
+            self._h = ctypes.c_void_p()
+
+
+class GroupMember:
+    def __init__(self, group, rank):
+        self._lib = group._lib
+        self._h = ctypes.c_void_p(self._lib.kx_group_join(group._h, rank))
+
+    def callback(self):
+        return ctypes.cast(self._lib.kx_group_allgather, ctypes.c_void_p), self._h
+
+    def close(self):
+        if self._h:
+            self._lib.kx_group_leave(self._h)
+            self._h = ctypes.c_void_p()
 
 
 class Shard:

@@ -367,7 +367,94 @@ def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         line = json.loads([x for x in r.stdout.decode().splitlines() if x.startswith('{"metric"')][-1])
         assert line["n_gpus"] == world and line["config"]["boundary_backend"] == "nccl"
+        assert line["config"]["boundary_driver"].startswith("kx_run_sharded")   # the library's own driver and RCCL communicator
         assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]
+
+
+def test_c_driver_shards_inside_one_process_and_in_the_binary(tmp_path):
+    """kx_run_sharded (include/kxhip.h): the boundary hand-off is run by the library itself.  (1) Three and five ranks as
+    threads of this process, exchange through kx_group_*: shards cut mid-line, a two-stage pipeline, a rejected input
+    (every rank reports the same global position).  (2) `BIN --gpus N < file > out` (KX_SHARD_SAME_DEVICE=1: the box has
+    one GPU): regular file and pipe on stdout, match error text and exit code."""
+    import subprocess
+    import threading
+    import torch
+    from kleenexlang_amd import build, program_path
+    from kleenexlang_amd.host import Group
+
+    def run_ranks(blob, data, world):
+        grp = Group(world)
+        L = (len(data) // world) // 4096 * 4096
+        outs, errs = [None] * world, [None] * world
+
+        def body(r):
+            try:
+                lo, hi = r * L, (len(data) if r == world - 1 else (r + 1) * L)
+                p = Program(blob)
+                t = torch.frombuffer(bytearray(data[lo:hi] or b"\0"), dtype=torch.uint8).to("cuda:0")
+                out = torch.empty(4 * (hi - lo) + 65536, dtype=torch.uint8, device="cuda:0")
+                mb = grp.member(r)
+                try:
+                    res = p.run_sharded(r, world, mb, t.data_ptr(), hi - lo, out.data_ptr(), out.numel())
+                    torch.cuda.synchronize()
+                    outs[r] = (int(res.out_offset), bytes(out[:int(res.out_len)].cpu().numpy().tobytes()), int(res.total_out))
+                finally:
+                    mb.close(); p.close()
+            except Exception as e:   # noqa: BLE001
+                errs[r] = e
+        th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        [x.start() for x in th]; [x.join() for x in th]
+        grp.close()
+        return outs, errs
+
+    blob = blob_of("apache_log")
+    data = workloads.generate("apache_log", 3 << 20, 11)
+    want = oracle.run(blob, data)
+    for world in (3, 5):
+        outs, errs = run_ranks(blob, data, world)
+        assert errs == [None] * world, errs
+        assert b"".join(o[1] for o in outs) == want and all(o[2] == len(want) for o in outs)
+        assert [o[0] for o in outs] == [sum(len(x[1]) for x in outs[:r]) for r in range(world)]
+    # two stages: the second stage's shards are the first stage's output slices
+    src2 = 'start: a >> b\na := (~/x/ "yy" | /[^x]/)*\nb := (~/yy/ "z" | /./)*\n'
+    blob2 = blob_of(src2)
+    d2 = bytes(random.Random(3).choice(b"xyab\n") for _ in range(200000))
+    outs, errs = run_ranks(blob2, d2, 3)
+    assert errs == [None] * 3 and b"".join(o[1] for o in outs) == oracle.run(blob2, d2)
+    # rejection: the global position, on every rank
+    cut = data.index(b"\n", 1 << 20) + 1
+    bad = data[:cut] + b"not a log line\n" + data[cut:]
+    outs, errs = run_ranks(blob, bad, 3)
+    assert all(isinstance(e, MatchError) for e in errs) and {e.pos for e in errs} == {oracle_fail_pos(blob, bad)}
+    # the binary
+    exe = tmp_path / "apache"
+    assert subprocess.run([os.path.join(build.OUT, "kexc"), "compile", "--quiet", program_path("apache_log"), "--out", str(exe)]).returncode == 0
+    src = tmp_path / "in.log"; src.write_bytes(data)
+    env = dict(os.environ, KX_SHARD_SAME_DEVICE="1")
+    for world in (2, 4):
+        out = tmp_path / ("out%d.json" % world)
+        with open(src, "rb") as fi, open(out, "wb") as fo:
+            fo.write(b"HDR\n"); fo.flush()
+            assert subprocess.run([str(exe), "--gpus", str(world)], stdin=fi, stdout=fo, env=env).returncode == 0
+            assert os.lseek(fo.fileno(), 0, os.SEEK_CUR) == 4 + len(want)
+        assert out.read_bytes() == b"HDR\n" + want
+        with open(src, "rb") as fi:
+            r = subprocess.run([str(exe), "--gpus", str(world)], stdin=fi, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0 and r.stdout == want
+    (tmp_path / "bad.log").write_bytes(bad)
+    with open(tmp_path / "bad.log", "rb") as fi:
+        r = subprocess.run([str(exe), "--gpus", "3"], stdin=fi, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 1 and r.stdout == b"" and r.stderr.endswith(b"Match error at input symbol %d!\n" % oracle_fail_pos(blob, bad))
+    r = subprocess.run([str(exe), "--gpus", "2"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)   # a pipe on stdin
+    assert r.returncode == 1 and b"regular file" in r.stderr
+
+
+def oracle_fail_pos(blob, data):
+    try:
+        oracle.run(blob, data)
+    except Exception as e:   # noqa: BLE001
+        return e.pos
+    raise AssertionError("input was accepted")
 
 
 def test_never_merging_program_resolves_in_linear_work():

@@ -65,6 +65,7 @@
 #define KXP_SYNC_UNKNOWN 0xFFFFFFFDu /* subset construction was capped here */
 
 /* action tokens (second byte after KXP_ESC) */
+#define KXP_MAX_ACTION_REGS 251u /* registers of a stage's action interpreter: 0..250 (a register index is one token byte) */
 #define KXP_ESC 0xFFu
 #define KXP_TOK_PUSH 0x00u
 #define KXP_TOK_POP 0x01u

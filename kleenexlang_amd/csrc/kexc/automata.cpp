@@ -77,7 +77,7 @@ FST constructTransducer(const RProg& rp, int start, bool tokens) {
         if (d.c.kind != 0) {
           if (!tokens)  // Commands.hs:165-168
             throw CompileError("Transducer contains action symbols - direct SST generation not supported");
-          if (d.c.kind != 1 && (d.c.arg < 0 || d.c.arg > 250)) throw CompileError("too many registers (at most 251)");
+          if (d.c.kind != 1 && (d.c.arg < 0 || d.c.arg >= (int)KXP_MAX_ACTION_REGS)) throw CompileError("too many registers (at most " + std::to_string(KXP_MAX_ACTION_REGS) + ")");
           out = d.c.kind == 1 ? std::string("\xFF\x00", 2) : std::string(d.c.kind == 2 ? "\xFF\x01" : "\xFF\x02", 2) + char(d.c.arg);
         } else if (tokens && (d.c.arg & 0xFF) == 0xFF) out = "\xFF\xFF";
         else out = std::string(1, char(d.c.arg));

@@ -61,6 +61,7 @@ void writeBinary(const std::string& out, const std::vector<uint8_t>& blob, const
   uint64_t bl = blob.size(), dl = dir.size();
   bin.write((const char*)&bl, 8); bin.write((const char*)&dl, 8); bin.write("KXRUNTRL", 8);
   bin.close();
+  if (!bin.good()) { unlink(out.c_str()); throw CompileError("write error on " + out + " (disk full?)"); }
   chmod(out.c_str(), 0755);
 }
 
@@ -222,6 +223,8 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       if (!P.maxleaves || P.maxleaves > 254) bad("maxleaves out of range");
       if (!P.class_of || !P.delta || !P.action || !P.final_action || !P.action_off || !P.const_off || !P.back_row || !P.nleaves || !P.final_leaf ||
           !P.back || !P.pconst_off || !P.init_const) bad("missing table");
+      if ((P.nactions && P.action_off[P.nactions] && !P.ops) || (P.nconsts && P.const_off[P.nconsts] && !P.const_pool) ||
+          (P.npconsts && P.pconst_off[P.npconsts] && !P.pconst_pool)) bad("missing table (micro-ops or constant pool)");
       StageTables t;
       t.nstates = (int)P.nstates; t.nclasses = (int)P.nclasses; t.q0 = (int)P.init_state; t.nregs = (int)P.nregs; t.maxleaves = (int)P.maxleaves;
       const size_t sc = (size_t)P.nstates * P.nclasses;
@@ -351,7 +354,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= t.pconsts.size())) bad("backward entry out of range");
       t.init_const.assign(P.init_const, P.init_const + P.maxleaves);
       for (uint32_t v : t.init_const) if (v >= P.npconsts) bad("initial constant out of range");
-      if (P.action_regs > 250) bad("too many action registers");
+      if (P.has_actions && P.action_regs > KXP_MAX_ACTION_REGS) bad("too many action registers (at most " + std::to_string(KXP_MAX_ACTION_REGS) + ")");
       t.act_regs = P.has_actions ? (int)P.action_regs : -1;
       buildSync(t);
       stages.push_back(std::move(t));
@@ -366,6 +369,8 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       std::ofstream f(srcout_path, std::ios::binary | std::ios::trunc);
       if (!f) throw CompileError(std::string("cannot write ") + srcout_path);
       f.write((const char*)blob.data(), blob.size());
+      f.close();
+      if (!f.good()) throw CompileError(std::string("write error on ") + srcout_path);
     }
     if (out_path && *out_path) {
       Dl_info di;

@@ -24,6 +24,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <unistd.h>
+#include "../../../include/kxp_format.h"
 
 namespace kexc {
 

@@ -28,7 +28,7 @@ res = {}
 for name, (src, line) in PROGRAMS.items():
     rnd = random.Random(5)
     base = b"".join(line(rnd) for _ in range(20000))
-    data = base * max(1, (16 << 20) // len(base))
+    data = base * max(1, (int(os.environ.get("KX_BENCH_MIB", "16")) << 20) // len(base))
     blob = host.compile_source(src)
     want = oracle.run(blob, data)
     prog = host.Program(blob, collect_timing=True)

@@ -564,6 +564,55 @@ def test_register_actions_on_the_engine(tmp_path):
     p.close()
 
 
+def test_action_post_pass_replays_independent_chunks_in_parallel(tmp_path, monkeypatch, capfd):
+    """the post-pass cuts the token stream at safe points (stack at the bottom buffer, every register
+    empty) and replays the chunks by thousands of waves (k_actions_chunks).  Tiny chunks here, so that a few hundred KB make
+    hundreds of them: line programs (cut after every line), the escaped byte FF next to cuts, two stages; programs without
+    safe points (one frame around everything, a register alive to the end) and with more than 32 registers fall back to
+    the one-wave replay; windows carry the state into a parallel replay; an 8 MiB stream with the default sizes."""
+    import subprocess
+    from kleenexlang_amd import build
+    from test_register_actions import PROGRAMS
+    monkeypatch.setenv("KX_ACT_PAR_MIN", "8192")
+    monkeypatch.setenv("KX_ACT_CHUNK", "2048")
+    monkeypatch.setenv("KX_DEBUG", "1")
+    rnd = random.Random(9)
+    words = lambda k: b"".join(bytes(rnd.choice(b"abcxyz") for _ in range(rnd.randint(0, 9))) + b"," + str(rnd.randint(0, 10 ** rnd.randint(1, 8))).encode() + b"\n" for _ in range(k))
+    many = 'main := (' + " ".join('r%d@/%s/' % (i, "ab"[i & 1]) for i in range(40)) + " " + " ".join("!r%d" % i for i in reversed(range(40))) + ' /\n/)*\n'
+    cases = [("swap_fields", PROGRAMS["swap_fields"], words(40000), True),
+             ("byte_ff", PROGRAMS["byte_ff"], bytes(rnd.choice(b"ab\xff\xff\xfe\n") for _ in range(300000)) + b"\n", True),
+             ("two_stage", PROGRAMS["two_stage"], bytes(rnd.choice(b"abcz") for _ in range(200000)), True),
+             ("long_lines", 'main := (l@/[^\n]*/ ~/\n/ "<" !l ">\n")*\n', b"".join(bytes(rnd.choice(b"abcdefgh \xff") for _ in range(rnd.randrange(0, 700))) + b"\n" for _ in range(800)), True),
+             ("nested", PROGRAMS["nested"], b"a" * 300000 + b"b" * 7000, False),
+             ("accumulate", PROGRAMS["accumulate"], b"".join(bytes(rnd.choice(b"abc") for _ in range(rnd.randint(1, 6))) + b" " for _ in range(4000)), False),
+             ("forty_registers", many, (b"ab" * 20 + b"\n") * 3000, False)]
+    kexc = os.path.join(build.OUT, "kexc")
+    for name, src, data, parallel in cases:
+        blob = blob_of(src)
+        want = oracle.run(blob, data)
+        p = Program(blob)
+        capfd.readouterr()
+        assert p.run_host(data) == want, name
+        err = capfd.readouterr().err
+        assert ("chunks of about" in err) == parallel, (name, err[-300:])
+        p.close()
+        if name in ("swap_fields", "byte_ff", "accumulate"):
+            path = tmp_path / (name + ".kex"); path.write_text(src)
+            exe = tmp_path / name
+            assert subprocess.run([kexc, "compile", "--quiet", str(path), "--out", str(exe)]).returncode == 0
+            for window in (30000, 1 << 30):
+                r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KX_WINDOW_BYTES=str(window)))
+                assert r.returncode == 0 and r.stdout == want, (name, window, r.stderr[-300:])
+    monkeypatch.delenv("KX_ACT_PAR_MIN"); monkeypatch.delenv("KX_ACT_CHUNK")
+    data = words(700000)
+    blob = blob_of(PROGRAMS["swap_fields"])
+    p = Program(blob)
+    capfd.readouterr()
+    assert p.run_host(data) == oracle.run(blob, data)
+    assert "chunks of about" in capfd.readouterr().err
+    p.close()
+
+
 def test_tables_beyond_16_bit_addressing_run_from_global_memory(monkeypatch):
     """a program whose image exceeds 64 KiB (make_danish-sized: ~1000 states x 28 classes) is not
     refused any more — its GENERAL kernel instances read the image from global memory with scaled handles

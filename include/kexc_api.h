@@ -67,7 +67,13 @@ typedef struct kexc_il_program {
   uint32_t ntables; const uint32_t* tbl_width; const uint8_t* tbl_data; const uint32_t* back_table;
 } kexc_il_program;
 
-/* `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per
+/* What a front end has to do to hand its pipeline over (INTEGRATION.md §1 has the Haskell): run the determinizer in singleton mode
+ * (`sstFromFST fst True`, Determinization.hs:233-257 — `--la=false`; a multi-symbol test of `--la=true`, SymbolicFST.hs:296-312, is not
+ * a row of a (state, class) table, and the two machines write the same bytes, Tests/Regression.hs:45-53) and read the annotation off
+ * the finished SST: its states are their own path trees and every transition's registers expand to the parent leaf's node
+ * positions followed by what the step appends (no change to the determinizer).
+ *
+ * `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per
  * program; Right = (oracle, action) pairs, programs[2i] and programs[2i+1] — accepted by the type, refused: the action
  * program (actionToSST, src/KMC/SymbolicSST/ActionSST.hs:47-104) is a register machine whose registers hold data (the
  * contents of `r@t`), not the pending output of undecided paths, so it has no path form.  Register actions reach the

@@ -167,6 +167,7 @@ kx_group* kx_group_create(int world);
 void kx_group_free(kx_group* g);
 kx_group_member* kx_group_join(kx_group* g, int rank);
 void kx_group_leave(kx_group_member* m);
+void kx_group_abort(kx_group* g);   /* a member that fails outside the protocol wakes the others: their all-gathers return an error */
 int kx_group_allgather(void* member, const void* send, void* recv, size_t bytes);         /* a kx_allgather_fn */
 
 #ifdef __cplusplus

@@ -77,15 +77,18 @@ struct kx_comm {
 struct kx_group {   // ranks = threads of one process
   int world;
   std::mutex m; std::condition_variable cv;
-  int arrived = 0; uint64_t gen = 0;
+  int arrived = 0; uint64_t gen = 0; bool aborted = false;
   std::vector<uint8_t> buf;
   explicit kx_group(int w) : world(w), buf((size_t)w * MSG_MAX) {}
-  void barrier() {
+  bool barrier() {   // false: a member gave up (its error would otherwise leave the others waiting for ever)
     std::unique_lock<std::mutex> lk(m);
     const uint64_t g = gen;
+    if (aborted) return false;
     if (++arrived == world) { arrived = 0; ++gen; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
+    else cv.wait(lk, [&] { return gen != g || aborted; });
+    return !aborted;
   }
+  void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }
 };
 struct kx_group_member { kx_group* g; int rank; };
 
@@ -153,11 +156,12 @@ int kx_group_allgather(void* ctx, const void* send, void* recv, size_t bytes) {
   if (!mb || bytes > MSG_MAX) return sErr(KX_E_ARG, "bad all-gather arguments");
   kx_group* g = mb->g;
   memcpy(g->buf.data() + (size_t)mb->rank * bytes, send, bytes);
-  g->barrier();
+  if (!g->barrier()) return sErr(KX_E_IO, "another rank of the group failed");
   memcpy(recv, g->buf.data(), bytes * (size_t)g->world);
-  g->barrier();
+  if (!g->barrier()) return sErr(KX_E_IO, "another rank of the group failed");
   return 0;
 }
+void kx_group_abort(kx_group* g) { if (g) g->abort(); }
 
 // ------------------------------------------------------------------------------------ the driver
 // records of the three exchanges
@@ -325,7 +329,7 @@ int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, i
     }
     if (!rcs[r]) {
       int rc = runSharded(prog, r, ngpus, kx_group_allgather, mb, d_in, len, nullptr, 0, &results[r], nullptr, &d_out);
-      if (rc) fail(rc, kx_last_error());
+      if (rc) { fail(rc, kx_last_error()); if (rc != KX_MATCH_ERROR) kx_group_abort(grp); }   // (a match error is seen by every rank; anything else by this one only)
     }
     if (!rcs[r]) {
       const uint64_t ol = results[r].out_len;

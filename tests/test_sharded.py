@@ -159,3 +159,50 @@ def test_hip_empty_last_and_empty_middle_shards():
                 s.end()
             assert b"".join(outs) == want, (prog, [len(p) for p in parts])
             for p in progs: p.close()
+
+
+def test_thread_group_allgather_and_abort():
+    """kx_group_* (the produced binary's `--gpus N`: ranks = threads, exchange through host memory): every member sees every
+    member's record in rank order, round after round; a member that gives up wakes the others instead of leaving them in the
+    barrier.  (Host code of libkxhip.so: runs without a GPU.)"""
+    import ctypes
+    import threading
+    from kleenexlang_amd import host
+    lib = host.load_engine()
+    lib.kx_group_allgather.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.kx_group_abort.argtypes = [ctypes.c_void_p]
+    world = 5
+    g = host.Group(world)
+    seen = [None] * world
+
+    def body(r):
+        mb = g.member(r)
+        got = []
+        for rnd in range(50):
+            rec = ctypes.create_string_buffer(bytes([r, rnd & 0xFF]) * 8, 16)
+            out = ctypes.create_string_buffer(16 * world)
+            assert lib.kx_group_allgather(mb._h, rec, out, 16) == 0
+            got.append(out.raw)
+        seen[r] = got
+        mb.close()
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for r in range(world):
+        for rnd in range(50):
+            assert seen[r][rnd] == b"".join(bytes([q, rnd]) * 8 for q in range(world))
+    g.close()
+    # abort: four members wait, the fifth gives up
+    g = host.Group(world)
+    rcs = [None] * world
+
+    def waiter(r):
+        mb = g.member(r)
+        rec = ctypes.create_string_buffer(16); out = ctypes.create_string_buffer(16 * world)
+        rcs[r] = lib.kx_group_allgather(mb._h, rec, out, 16)
+        mb.close()
+    th = [threading.Thread(target=waiter, args=(r,)) for r in range(world - 1)]
+    [t.start() for t in th]
+    lib.kx_group_abort(g._h)
+    [t.join(timeout=20) for t in th]
+    assert all(not t.is_alive() for t in th) and all(rc is not None and rc != 0 for rc in rcs[:world - 1])
+    g.close()

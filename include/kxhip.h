@@ -134,7 +134,7 @@ void kx_shard_end(kx_shard* s);
  * kx_run_sharded runs every pipeline stage over the rank's shard and takes part in the boundary hand-off — four
  * all-gathers of fixed-size records per stage (40, 40, 272 and 8 bytes per rank), nothing else crosses ranks — through
  * the all-gather it is given:
- *   kx_comm_*   RCCL: `ncclAllGather` on the communicator's own pinned buffers and stream (xGMI between the GPUs of a node;
+ *   kx_comm_*   RCCL: `ncclAllGather` on the communicator's own device buffers and stream (xGMI between the GPUs of a node;
  *               librccl is dlopen'ed).  Rank 0 makes the 128-byte id (kx_comm_unique_id) and the launcher hands it to every
  *               rank (ncclGetUniqueId / ncclCommInitRank's contract); every rank then calls kx_comm_init on its device.
  *   kx_group_*  the threads of one process (the produced binary's `--gpus N`): exchange through host memory.

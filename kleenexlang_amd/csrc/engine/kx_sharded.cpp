@@ -9,7 +9,7 @@
 // Per pipeline stage a rank runs the kx_shard_* phases on its own shard and takes part in four all-gathers of fixed-size
 // records (40, 40, 272 and 8 bytes per rank): states forward (before and after the shard heads are fixed), leaves backward,
 // output sizes.  The all-gather is a callback:
-//   kx_comm_*   RCCL (`ncclAllGather` on pinned host buffers, its own communicator; librccl is dlopen'ed so that the
+//   kx_comm_*   RCCL (`ncclAllGather` on small device buffers of its own communicator; librccl is dlopen'ed so that the
 //               engine library has no link-time dependency on it) — one process per GPU, xGMI between them;
 //   kx_group_*  threads of one process (the produced binary's `--gpus N`), exchange through host memory.
 // With one rank no exchange happens at all.
@@ -70,7 +70,8 @@ constexpr size_t MSG_MAX = 512;   // largest per-rank record of the protocol (27
 
 struct kx_comm {
   void* nccl = nullptr; int rank = 0, world = 1;
-  uint8_t *send = nullptr, *recv = nullptr;   // pinned host memory: device-visible, so RCCL takes it directly (no staging copies)
+  uint8_t *send = nullptr, *recv = nullptr;       // pinned host staging
+  uint8_t *d_send = nullptr, *d_recv = nullptr;   // device buffers: what RCCL is handed (the documented kind of buffer)
   hipStream_t stream = nullptr;
 };
 
@@ -115,6 +116,7 @@ int kx_comm_init(kx_comm** out, int rank, int world, const void* id128) {
     if (rc) { delete c; return sErr(KX_E_HIP, std::string("ncclCommInitRank: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "failed")); }
     if (hipHostMalloc((void**)&c->send, MSG_MAX, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void**)&c->recv, MSG_MAX * (size_t)world, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->d_send, MSG_MAX) != hipSuccess || hipMalloc((void**)&c->d_recv, MSG_MAX * (size_t)world) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
       delete c; return sErr(KX_E_HIP, "cannot allocate the communicator's buffers");
     }
@@ -128,6 +130,8 @@ void kx_comm_free(kx_comm* c) {
   if (c->nccl) rccl().CommDestroy(c->nccl);
   if (c->send) (void)hipHostFree(c->send);
   if (c->recv) (void)hipHostFree(c->recv);
+  if (c->d_send) (void)hipFree(c->d_send);
+  if (c->d_recv) (void)hipFree(c->d_recv);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -138,8 +142,10 @@ int kx_comm_allgather(void* ctx, const void* send, void* recv, size_t bytes) {
   if (!c || bytes > MSG_MAX) return sErr(KX_E_ARG, "bad all-gather arguments");
   if (c->world == 1) { memcpy(recv, send, bytes); return 0; }
   memcpy(c->send, send, bytes);
-  int rc = rccl().AllGather(c->send, c->recv, bytes, NCCL_UINT8, c->nccl, c->stream);
+  if (hipMemcpyAsync(c->d_send, c->send, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return sErr(KX_E_HIP, "hipMemcpyAsync failed");
+  int rc = rccl().AllGather(c->d_send, c->d_recv, bytes, NCCL_UINT8, c->nccl, c->stream);
   if (rc) return sErr(KX_E_HIP, std::string("ncclAllGather: ") + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "failed"));
+  if (hipMemcpyAsync(c->recv, c->d_recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return sErr(KX_E_HIP, "hipMemcpyAsync failed");
   if (hipStreamSynchronize(c->stream) != hipSuccess) return sErr(KX_E_HIP, "hipStreamSynchronize after ncclAllGather failed");
   memcpy(recv, c->recv, bytes * (size_t)c->world);
   return 0;

@@ -76,6 +76,30 @@ def test_corrupt_and_truncated_blobs_are_refused_not_read_out_of_bounds():
             except EngineError:
                 refused += 1
         assert refused > 100, refused
+        # single bytes the 32-bit mutations do not reach: a byte class beyond the class count, a state without
+        # leaves, a final leaf beyond the state's leaves — each would index past a table on the device
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import kxp
+        st = kxp.parse(blob)[0]
+        cls_off = hdr + 64
+        b = bytearray(blob); b[cls_off + ord("z")] = st.nclasses
+        with pytest.raises(EngineError, match="byte class"):
+            host.validate_blob(bytes(b))
+        sc = st.nstates * st.nclasses
+        pad4 = lambda n: (n + 3) & ~3
+        nact = struct.unpack_from("<I", blob, hdr + 5 * 4)[0]; nops = struct.unpack_from("<I", blob, hdr + 6 * 4)[0]
+        nconsts = struct.unpack_from("<I", blob, hdr + 7 * 4)[0]; cpl = struct.unpack_from("<I", blob, hdr + 8 * 4)[0]
+        nl_off = cls_off + 256 + pad4(sc * 2) + sc * 4 + st.nstates * 4 + (nact + 1) * 4 + nops * 8 + (nconsts + 1) * 4 + pad4(cpl) + sc * 4
+        assert bytes(blob[nl_off:nl_off + st.nstates]) == bytes(st.nleaves)      # (the offsets above are the format's)
+        b = bytearray(blob); b[nl_off + st.q0] = 0
+        with pytest.raises(EngineError, match="leaf count"):
+            host.validate_blob(bytes(b))
+        fin = [q for q in range(st.nstates) if st.fin_leaf[q] != 0xFF]
+        if fin:
+            b = bytearray(blob); b[nl_off + pad4(st.nstates) + fin[0]] = st.nleaves[fin[0]]
+            with pytest.raises(EngineError, match="leaf count"):
+                host.validate_blob(bytes(b))
 
 
 def test_produced_binary_refuses_a_corrupt_trailer(tmp_path):

@@ -50,8 +50,22 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    // the process may already hold an RCCL (PyTorch ships one): use that; else the system's
+    // the process may already hold an RCCL (PyTorch ships one, built against the HIP runtime it also ships): use that very
+    // library — by symbol if it is globally visible, else by the path it is mapped from — and only otherwise the system's
     void* h = dlsym(RTLD_DEFAULT, "ncclAllGather") ? RTLD_DEFAULT : nullptr;
+    if (!h) {
+      if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char line[4096];
+        while (!h && fgets(line, sizeof line, f)) {
+          char* path = strchr(line, '/');
+          if (!path) continue;
+          path[strcspn(path, "\n")] = 0;
+          const char* base = strrchr(path, '/');
+          if (base && strncmp(base + 1, "librccl.so", 10) == 0) h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
+        }
+        fclose(f);
+      }
+    }
     if (!h) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) return;
     r.GetUniqueId = (int (*)(NcclId*))dlsym(h, "ncclGetUniqueId");

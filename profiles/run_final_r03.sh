@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-3 evidence of the final engine (run on the GPU box through gpurun): GPU test suite, the three 10 GiB bench lines,
+# rocprofv3 kernel stats + HBM traffic (collect.sh), SQ counters (collect_sq.sh), soak.  usage: profiles/run_final_r03.sh TAG
+ulimit -c 0; export HSA_COREDUMP_PATTERN=/dev/null
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03z}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_pytest.txt 2>&1; tail -2 $O/gpu_pytest.txt
+for p in apache_log csv2json iso_datetime_to_json; do
+  timeout 900 python bench.py --program $p --steps 10 --warmup 2 $([ $p = apache_log ] || echo --no-cpu) > $O/bench_$p.json 2> $O/bench_$p.err
+  python -c "import json; d=json.loads(open('$O/bench_$p.json').read()); print('$p', d['value'], d['ms_per_step'], d['kernels_ms'], d['output_checked_bit_exact'])"
+done
+bash profiles/collect.sh $TAG > $O/collect.log 2>&1; tail -3 $O/collect.log
+bash profiles/collect_sq.sh ${TAG}_sq > $O/collect_sq.log 2>&1; tail -3 $O/collect_sq.log
+SOAK_LO=5000 SOAK_HI=6500 timeout 1500 python tests/soak/soak_engine.py > $O/soak_engine.txt 2>&1; tail -2 $O/soak_engine.txt
+timeout 1200 python tests/soak/soak_windows.py > $O/soak_windows.txt 2>&1; tail -1 $O/soak_windows.txt
+python profiles/actions_bench.py > $O/actions_16m.json 2>/dev/null; KX_BENCH_MIB=1024 python profiles/actions_bench.py > $O/actions_1g.json 2>/dev/null; tail -c 400 $O/actions_1g.json

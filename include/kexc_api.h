@@ -65,13 +65,31 @@ typedef struct kexc_il_program {
    * none; not together with the copy bit); NULL when ntables == 0.  The engine's tables hold no symbol-indexed output:
    * kexc_emit_pipeline refines the byte classes until every table is constant on each class and turns op 4 into op 1. */
   uint32_t ntables; const uint32_t* tbl_width; const uint8_t* tbl_data; const uint32_t* back_table;
+  /* Block form — `--la=true`, the reference's default.  A block then tests WORDS: `IfI (avail>=n && p_0(next[0]) && … &&
+   * p_{n-1}(next[n-1])) (updates ++ [ConsumeI n, GotoI s])`, nested by common prefix, longer words first (prefixTests /
+   * ldp, SymbolicFST.hs:264-312; the kv-tree of tests, SSTCompiler.hs:96-135) — not a row of a (state, class) table.
+   * ntests != 0 selects this form: the tests come with their annotation and the tables are built HERE from the
+   * annotation (one symbol per step again, writing what the word machine writes; kexc.h: leafGraph).  Read then:
+   * nstates, init_state, maxleaves, nleaves, final_leaf, the path-constant pool, init_const, has_actions/action_regs,
+   * and
+   *   test_block[t], test_target[t], test_len[t]   the block, its GotoI target, n of ConsumeI n (1..255)
+   *   test_preds     32 bytes per symbol of every test (tests in order, symbols in order): bit b of the 256-bit set,
+   *                  least significant byte first = byte b passes
+   *   test_back      one row of maxleaves entries per symbol of every test, in the same order: entry [leaf of the target]
+   *                  of the row of symbol i = parent leaf in the block's tree (row 0 only) | symbol i is copied << 8 |
+   *                  path constant appended after symbol i << 9
+   * class_of … back and the register-form arrays may be NULL (the blocks' register updates state the same function a
+   * second time and are not read); AppendTblI does not occur (tables belong to the coder, whose tests — ranges split to
+   * single symbols — are marshalled like any others).  Within a block, tests of equal length must be disjoint. */
+  uint32_t ntests; const uint32_t* test_block; const uint32_t* test_target; const uint32_t* test_len;
+  const uint8_t* test_preds; const uint32_t* test_back;
 } kexc_il_program;
 
-/* What a front end has to do to hand its pipeline over (INTEGRATION.md §1 has the Haskell): run the determinizer in singleton mode
- * (`sstFromFST fst True`, Determinization.hs:233-257 — `--la=false`; a multi-symbol test of `--la=true`, SymbolicFST.hs:296-312, is not
- * a row of a (state, class) table, and the two machines write the same bytes, Tests/Regression.hs:45-53) and read the annotation off
- * the finished SST: its states are their own path trees and every transition's registers expand to the parent leaf's node
- * positions followed by what the step appends (no change to the determinizer).
+/* What a front end has to do to hand its pipeline over (INTEGRATION.md §1 has the Haskell): read the annotation off the finished
+ * SST — its states are their own path trees and every transition's registers expand to the parent leaf's node positions followed
+ * by what the step appends (no change to the determinizer) — and marshal it: with `--la=false` (`sstFromFST fst True`,
+ * Determinization.hs:233-257) as the (state, class) tables above, with the default `--la=true` as the block form (ntests).
+ * The two machines write the same bytes (Tests/Regression.hs:45-53); so do the tables built from either.
  *
  * `type Pipeline = Either [Program] [(Program, Program)]` (IL.hs:90): Left = direct / coder pipelines, one phase per
  * program; Right = (oracle, action) pairs, programs[2i] and programs[2i+1] — accepted by the type, refused: the action
@@ -103,6 +121,17 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
  * register actions in direct mode: Commands.hs:57-62,165-168). */
 int kexc_compile(const char* source, size_t source_len, const char* source_name, int opt_level,
                  unsigned char** blob, size_t* blob_len);
+
+/* kexc_compile with the flags spelled out.  lookahead = `--la`: non-zero builds the lookahead machine the way the reference does
+ * (word tests: prefixTests, SymbolicFST.hs:296-312; kills and consumeTreeMany, Determinization.hs:213-257) and then the tables
+ * from its path form, exactly as kexc_emit_pipeline does for a block-form program.  regex: non-zero = kexc_compile_regex. */
+int kexc_compile_flags(const char* source, size_t source_len, const char* source_name, int opt_level, int lookahead, int regex,
+                       unsigned char** blob, size_t* blob_len);
+
+/* Test support: the lookahead machine of every stage in path form, JSON:
+ * [{"init","action_regs" (-1: none),"init_path":[[bytes]..],"states":[{"nleaves","final_leaf","edges":[{"to","word":[[32 bytes]..],
+ *   "path":[{"parent","steps":[[copy,[bytes]]..]}..]}..]}..]}] */
+int kexc_dump_words(const char* source, size_t source_len, const char* source_name, int regex, char** json, size_t* json_len);
 
 /* `--backend=c`: the same program printed as C in the reference's generated
  * shape (C.hs:72-83,267-311,486-493), to be compiled together with a `crt.c`

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <deque>
 #include <functional>
+#include <tuple>
 
 #include "kexc.h"
 
@@ -251,7 +252,7 @@ struct Determinizer {
     if (r) reduceTree(*r);
     return r;
   }
-  MTree consumeTree(const Tree& t, const ByteSet& p) {  // Determinization.hs:108-114
+  MTree consumeTree(const Tree& t, const ByteSet& p, int idx = 0) {  // Determinization.hs:108-114; idx = `inj i`
     std::set<int> vis;
     MTree r = bindTree(t, [&](int q, int tag) -> MTree {
       const FST::Sym* hit = nullptr;
@@ -262,7 +263,7 @@ struct Determinizer {
       if (!hit) return std::nullopt;
       if (vis.count(hit->to)) return std::nullopt;
       vis.insert(hit->to);
-      Tree n; n.st = hit->to; n.tag = tag; n.out = {funcAtom(hit->copy ? 0 : 1)};
+      Tree n; n.st = hit->to; n.tag = tag; n.out = {funcAtom(hit->copy ? 0 : 1)}; n.out[0].sym = idx;
       return n;
     });
     if (r) reduceTree(*r);
@@ -456,6 +457,270 @@ SST determinize(const FST& f) {
   }
   sst.nregs = (int)varIds.size();
   return sst;
+}
+
+// ================================================================ --la=true
+// sstFromFST … singletonMode=False (Determinization.hs:233-257): the same saturation as determinize(), but a state's
+// tests are words — prefixTests (SymbolicFST.hs:296-312) — and each test first kills the leaves whose longest
+// deterministic prefix it does not entail.  Only the path form is kept: it is all the engine's back end needs, and
+// it is what kexc_emit_pipeline takes from a front end that compiles with the reference's default flags.
+WordSST determinizeWords(const FST& f) {
+  Determinizer D(f);
+  WordSST w;
+  std::map<std::string, int> ids;
+  std::vector<Tree> skels;
+  std::deque<int> work;
+  auto intern = [&](const Tree& skel) {
+    std::string k; shapeKey(skel, k);
+    auto it = ids.find(k);
+    if (it != ids.end()) return it->second;
+    int id = (int)skels.size();
+    ids[k] = id; skels.push_back(skel); w.states.emplace_back(); work.push_back(id);
+    if (skels.size() > 60000) throw CompileError("SST has more than 60000 states");
+    return id;
+  };
+  std::function<void(const Tree&, Tree&)> skeleton = [&](const Tree& t, Tree& s) {
+    s.out = {varAtom(0)}; s.tip = t.tip; s.st = t.st; s.tag = -1;
+    s.kids.assign(t.kids.size(), Tree());
+    for (size_t m = 0; m < t.kids.size(); ++m) skeleton(t.kids[m], s.kids[m]);
+  };
+  // rightInputClosure (SymbolicFST.hs:281-294): the ε-free states below q, no output
+  std::map<int, std::set<int>> clMemo;
+  auto inputClosure = [&](int q) -> const std::set<int>& {
+    auto it = clMemo.find(q);
+    if (it != clMemo.end()) return it->second;
+    std::set<int> out, vis{q};
+    std::vector<int> st{q};
+    while (!st.empty()) {
+      int x = st.back(); st.pop_back();
+      if (f.eps[x].empty()) { out.insert(x); continue; }
+      for (auto& e : f.eps[x]) if (vis.insert(e.to).second) st.push_back(e.to);
+    }
+    return clMemo[q] = out;
+  };
+  auto predsOf = [&](const std::set<int>& ctx) {   // coarsestPredicateSet
+    std::set<ByteSet> ps;
+    for (int q : ctx) for (auto& e : f.sym[q]) ps.insert(e.pred);
+    return coarsestPartition(std::vector<ByteSet>(ps.begin(), ps.end()));
+  };
+  auto stepAll = [&](const ByteSet& p, const std::set<int>& ctx) {   // SymbolicFST.hs:274-278
+    std::set<int> out;
+    for (int q : ctx) for (auto& e : f.sym[q]) if (p.subsetOf(e.pred)) { auto& c = inputClosure(e.to); out.insert(c.begin(), c.end()); }
+    return out;
+  };
+  auto ldp = [&](std::set<int> ctx, int q) {   // SymbolicFST.hs:264-272; the cap only bounds a pathological cycle of symbol edges
+    std::vector<ByteSet> word;
+    while (word.size() < 255 && f.eps[q].empty() && f.sym[q].size() == 1) {
+      const ByteSet& p = f.sym[q][0].pred;
+      auto part = predsOf(ctx);
+      if (std::find(part.begin(), part.end(), p) == part.end()) break;
+      word.push_back(p);
+      ctx = stepAll(p, ctx);
+      q = f.sym[q][0].to;
+    }
+    return word;
+  };
+  {
+    Tree t0; t0.st = f.init; t0.out = {varAtom(0)};
+    w.init = intern(t0);
+  }
+  while (!work.empty()) {
+    const int sid = work.front(); work.pop_front();
+    MTree tcl = D.closeTree(skels[sid]);
+    if (!tcl) continue;
+    int nl = 0; tagLeaves(*tcl, nl);
+    std::vector<const Tree*> leaves; leavesOf(*tcl, leaves);
+    w.states[sid].nleaves = nl;
+    if (sid == w.init) {
+      std::function<void(const Tree&, std::string)> walk = [&](const Tree& t, std::string acc) {
+        for (auto& a : t.out) if (a.kind == Atom::CONST) acc += a.bytes;
+        if (t.tip) { w.init_path.push_back(acc); return; }
+        for (auto& k : t.kids) walk(k, acc);
+      };
+      walk(*tcl, "");
+    }
+    if (MTree e = D.eofTree(*tcl); e && e->tip) w.states[sid].final_leaf = e->tag;
+    // the closed tree with every output forgotten: what a step appends is then all that is on its paths
+    Tree closed = *tcl;
+    std::function<void(Tree&)> mark = [&](Tree& t) { t.out = {varAtom(0)}; for (auto& k : t.kids) mark(k); };
+    mark(closed);
+    // prefixTests (SymbolicFST.hs:296-312)
+    std::set<int> ctx;
+    for (auto* l : leaves) ctx.insert(l->st);
+    std::vector<std::pair<std::vector<ByteSet>, int>> ldps;
+    std::set<std::vector<ByteSet>> tests;
+    for (const ByteSet& p : predsOf(ctx)) tests.insert({p});
+    for (auto* l : leaves) { ldps.push_back({ldp(ctx, l->st), l->st}); tests.insert(ldps.back().first); }
+    for (const auto& ps : tests) {
+      if (ps.empty()) continue;
+      std::set<int> kills;
+      for (auto& [lw, q] : ldps) {   // entails: the leaf's prefix must be a prefix of the test
+        bool ok = lw.size() <= ps.size();
+        for (size_t i = 0; ok && i < lw.size(); ++i) ok = ps[i] == lw[i];
+        if (!ok) kills.insert(q);
+      }
+      MTree cur = bindTree(closed, [&](int q, int tag) -> MTree {   // killTree (Determinization.hs:122-124,147-151)
+        if (kills.count(q)) return std::nullopt;
+        Tree n; n.st = q; n.tag = tag; return n;
+      });
+      if (cur) reduceTree(*cur);
+      for (size_t i = 0; cur && i < ps.size(); ++i) {   // consumeTreeMany (Determinization.hs:213-228)
+        MTree a = D.closeTree(*cur);
+        MTree b = a ? D.consumeTree(*a, ps[i], (int)i) : std::nullopt;
+        cur = b ? D.closeTree(*b) : std::nullopt;
+      }
+      if (!cur) continue;
+      WordEdge edge; edge.word = ps;
+      std::function<void(const Tree&, UpdateString)> walk = [&](const Tree& t, UpdateString acc) {
+        acc.insert(acc.end(), t.out.begin(), t.out.end());
+        if (!t.tip) { for (auto& k : t.kids) walk(k, acc); return; }
+        WordPath wp; wp.parent = t.tag; wp.steps.resize(ps.size());
+        int at = -1;
+        for (auto& a : acc) {
+          if (a.kind == Atom::VAR) { if (at >= 0) throw CompileError("internal: register after new output on a path"); continue; }
+          if (a.kind == Atom::FUNC) {
+            if (a.sym != at + 1) throw CompileError("internal: symbols of a test out of order on a path");
+            at = a.sym; wp.steps[(size_t)at].copy = a.func == 0;
+          } else if (at < 0) { if (!a.bytes.empty()) throw CompileError("internal: output before the first symbol of a test"); }
+          else wp.steps[(size_t)at].bytes += a.bytes;
+        }
+        if (at + 1 != (int)ps.size()) throw CompileError("internal: a path of a test does not read all its symbols");
+        edge.path.push_back(std::move(wp));
+      };
+      walk(*cur, {});
+      Tree skel; skeleton(*cur, skel);
+      edge.to = intern(skel);
+      w.states[sid].edges.push_back(std::move(edge));
+    }
+  }
+  return w;
+}
+
+FST leafGraph(const WordSST& w) {
+  using Word = std::vector<ByteSet>;
+  using Cons = std::set<Word>;   // words the input must NOT start with from here: longer tests that would have fired instead
+  FST g;
+  auto fresh = [&]() { g.eps.emplace_back(); g.sym.emplace_back(); g.is_final.push_back(0); return g.nstates++; };
+  if (w.init < 0 || (size_t)w.init >= w.states.size() || (int)w.init_path.size() != w.states[(size_t)w.init].nleaves)
+    throw CompileError("initial state and initial path constants disagree");
+  for (auto& st : w.states)
+    for (auto& e : st.edges) {
+      if (e.to < 0 || (size_t)e.to >= w.states.size() || (int)e.path.size() != w.states[(size_t)e.to].nleaves || e.word.empty())
+        throw CompileError("a test's target and its leaf annotation disagree");
+      for (auto& p : e.word) if (p.empty()) throw CompileError("empty predicate in a test");
+      for (auto& wp : e.path) if (wp.steps.size() != e.word.size() || wp.parent < 0 || wp.parent >= st.nleaves) throw CompileError("a leaf's steps and its test disagree");
+    }
+  // A node = (state, leaf, constraint).  A block takes the LONGEST of its tests that matches (the nested IfI's of
+  // compileTransitions, SSTCompiler.hs:113-127, try the extensions of a word before the word's own action), so the
+  // alternative of a shorter test carries the longer ones as a constraint on what follows: with it every input takes
+  // exactly the test the word machine takes, and no path of the transducer is represented twice.
+  std::map<std::tuple<int, int, Cons>, int> ids;
+  std::deque<std::tuple<int, int, Cons>> work;
+  auto nodeOf = [&](int q, int l, const Cons& c) {
+    auto key = std::make_tuple(q, l, c);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    if (ids.size() > 2000000) throw CompileError("the unrolled lookahead machine has more than 2000000 nodes");
+    const int id = fresh();
+    ids.emplace(key, id); work.push_back(key);
+    return id;
+  };
+  g.init = fresh();
+  for (int l = 0; l < w.states[(size_t)w.init].nleaves; ++l) {
+    const int n = nodeOf(w.init, l, {});   // (sequenced: nodeOf grows g.eps)
+    g.eps[(size_t)g.init].push_back({w.init_path[(size_t)l], n});
+  }
+
+  // A node about to read symbol i of its alternatives reads it ONCE where it can — one symbol edge per distinct predicate
+  // (blocks of one partition: equal or disjoint), the alternatives behind it in their order — so that a leaf of the word
+  // machine stays one leaf of the table machine; where alternatives do not agree (overlapping predicates, different copy
+  // flags: no machine of the reference's does that) they are read apart, in order.
+  struct Alt { const WordEdge* e; int lt; Cons c; };
+  struct Group { ByteSet pred; bool copy; std::vector<Alt> alts; };
+  std::function<void(int, const std::vector<Alt>&, size_t, bool)> fill;
+  auto after = [&](int m, const std::vector<Alt>& alts, size_t i) {   // m: symbol i has been read; what follows it, in order
+    for (size_t k = 0; k < alts.size();) {
+      const WordEdge& e = *alts[k].e;
+      const std::string& bytes = e.path[(size_t)alts[k].lt].steps[i].bytes;
+      if (e.word.size() == i + 1) { const int n = nodeOf(e.to, alts[k].lt, alts[k].c); g.eps[(size_t)m].push_back({bytes, n}); ++k; continue; }
+      std::vector<Alt> run;
+      while (k < alts.size() && alts[k].e->word.size() > i + 1 && alts[k].e->path[(size_t)alts[k].lt].steps[i].bytes == bytes) run.push_back(alts[k++]);
+      const int n = fresh();
+      g.eps[(size_t)m].push_back({bytes, n});
+      fill(n, run, i + 1, false);
+    }
+  };
+  fill = [&](int node, const std::vector<Alt>& alts, size_t i, bool fin) {
+    std::vector<std::vector<Group>> runs(1);
+    for (const Alt& a : alts) {
+      const ByteSet& p = a.e->word[i];
+      const bool c = a.e->path[(size_t)a.lt].steps[i].copy;
+      Group* hit = nullptr; bool clash = false;
+      for (auto& gr : runs.back()) {
+        if (gr.pred == p) { if (gr.copy == c) hit = &gr; else clash = true; }
+        else if (!(gr.pred & p).empty()) clash = true;
+      }
+      if (clash) { runs.emplace_back(); hit = nullptr; }
+      if (hit) hit->alts.push_back(a); else runs.back().push_back(Group{p, c, {a}});
+    }
+    auto reader = [&](int r, const std::vector<Group>& run) {
+      for (const Group& gr : run) {
+        // the predicate, cut along the first symbols of the constraints of its alternatives
+        std::set<ByteSet> firsts;
+        for (auto& a : gr.alts) for (auto& f : a.c) firsts.insert(f[0]);
+        std::vector<ByteSet> cuts(firsts.begin(), firsts.end()), parts;
+        if (cuts.empty()) parts.push_back(gr.pred);
+        else {
+          std::map<std::vector<bool>, ByteSet> blocks;
+          for (int b = 0; b < 256; ++b) {
+            if (!gr.pred.has(b)) continue;
+            std::vector<bool> sig(cuts.size());
+            for (size_t x = 0; x < cuts.size(); ++x) sig[x] = cuts[x].has(b);
+            blocks[sig].add(b);
+          }
+          for (auto& kv : blocks) parts.push_back(kv.second);
+        }
+        for (const ByteSet& part : parts) {
+          std::vector<Alt> live;
+          for (auto& a : gr.alts) {
+            Cons next; bool dead = false;
+            for (auto& f : a.c) {
+              if (!part.subsetOf(f[0])) continue;   // the forbidden word does not start like this: it no longer applies
+              if (f.size() == 1) { dead = true; break; }
+              next.insert(Word(f.begin() + 1, f.end()));
+            }
+            if (!dead) live.push_back(Alt{a.e, a.lt, std::move(next)});
+          }
+          if (live.empty()) continue;
+          const int m = fresh();
+          g.sym[(size_t)r].push_back({part, gr.copy, m});
+          after(m, live, i);
+        }
+      }
+    };
+    if (runs.size() == 1) { reader(node, runs[0]); if (fin) g.is_final[(size_t)node] = 1; return; }
+    for (auto& run : runs) { const int r = fresh(); g.eps[(size_t)node].push_back({"", r}); reader(r, run); }
+    if (fin) { const int f = fresh(); g.is_final[(size_t)f] = 1; g.eps[(size_t)node].push_back({"", f}); }
+  };
+  while (!work.empty()) {
+    auto [q, lp, c] = work.front(); work.pop_front();
+    const int node = ids.at(std::make_tuple(q, lp, c));
+    const WordState& st = w.states[(size_t)q];
+    std::vector<const WordEdge*> order;
+    for (auto& e : st.edges) order.push_back(&e);
+    std::stable_sort(order.begin(), order.end(), [](const WordEdge* a, const WordEdge* b) { return a->word.size() > b->word.size(); });
+    std::vector<Alt> alts;
+    for (const WordEdge* e : order) {
+      Cons mine = c;
+      for (const WordEdge* o : order) {   // the tests that extend this one
+        if (o->word.size() <= e->word.size()) break;
+        if (std::equal(e->word.begin(), e->word.end(), o->word.begin())) mine.insert(o->word);
+      }
+      for (size_t lt = 0; lt < e->path.size(); ++lt) if (e->path[lt].parent == lp) alts.push_back(Alt{e, (int)lt, mine});
+    }
+    fill(node, alts, 0, st.final_leaf == lp);
+  }
+  return g;
 }
 
 // ================================================================== optimize

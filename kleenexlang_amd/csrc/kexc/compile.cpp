@@ -22,12 +22,13 @@ Compiled compileSource(const std::string& src, const std::string& srcname, const
     // kexc.hs:46-48): the program's output is the code of the greedy parse, not a rewriting of the input
     RProg rp = parseRegexProgram(src, srcname);
     FST f = oracleTransducer(constructTransducer(rp, rp.pipeline[0], false));
+    if (o.la) f = leafGraph(determinizeWords(f));
     SST sst = determinize(f);
     optimizeSST(sst, o.opt);
     out.sst_states.push_back((int)sst.states.size());
     out.stages.push_back(lower(sst, sst));
     std::ostringstream info;                  // Commands.hs:258-266
-    info << "Options:\\n--opt " << o.opt << " --la=false --wordsize 8\\n\\nSource file: " << srcname << "\\nOracle SST states:  " << out.sst_states[0];
+    info << "Options:\\n--opt " << o.opt << " --la=" << (o.la ? "true" : "false") << " --wordsize 8\\n\\nSource file: " << srcname << "\\nOracle SST states:  " << out.sst_states[0];
     out.info = info.str();
     return out;
   }
@@ -36,14 +37,17 @@ Compiled compileSource(const std::string& src, const std::string& srcname, const
   for (int start : rp.pipeline) {
     const bool acts = stageHasActions(rp, start);   // register actions: in-band tokens + the action post-pass
     FST f = constructTransducer(rp, start, acts && o.act);   // (--act=false = compileDirect: refuses them, Commands.hs:165-168)
-    SST sst = determinize(f);                 // --la=false semantics (singletonMode)
+    // --la=true: the lookahead machine (word tests) is built as the reference builds it, then unrolled over its leaves
+    // into single-symbol steps — the tables stay (state, class) tables and write what the lookahead machine writes
+    if (o.la) f = leafGraph(determinizeWords(f));
+    SST sst = determinize(f);                 // singletonMode
     optimizeSST(sst, o.opt);
     out.sst_states.push_back((int)sst.states.size());
     out.stages.push_back(lower(sst, sst));
     if (acts) out.stages.back().act_regs = (int)rp.regnames.size();
   }
   std::ostringstream info;                    // Commands.hs:191-199
-  info << "Options:\\n--opt " << o.opt << " --la=false --act=" << (o.act ? "true" : "false") << "\\n\\nSource file: " << srcname
+  info << "Options:\\n--opt " << o.opt << " --la=" << (o.la ? "true" : "false") << " --act=" << (o.act ? "true" : "false") << "\\n\\nSource file: " << srcname
        << "\\nSST states:  ";
   for (size_t i = 0; i < out.sst_states.size(); ++i) info << (i ? ", " : "") << out.sst_states[i];
   out.info = info.str();
@@ -167,6 +171,80 @@ int kexc_dump_fst(const char* source, size_t source_len, const char* source_name
   }
 }
 
+// kexc_compile with the flags spelled out: lookahead = `--la`, regex = the source is one regular expression (bit-coder)
+int kexc_compile_flags(const char* source, size_t source_len, const char* source_name, int opt_level, int lookahead, int regex,
+                       unsigned char** blob, size_t* blob_len) {
+  try {
+    kexc::Options o; o.opt = opt_level; o.la = lookahead != 0; o.regex = regex != 0;
+    auto c = kexc::compileSource(std::string(source, source_len), source_name ? source_name : "<memory>", o);
+    auto b = kexc::writeBlob(c.stages, c.info);
+    *blob = (unsigned char*)dupBytes(b.data(), b.size());
+    *blob_len = b.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
+// The lookahead machine (`--la=true`) of every stage in its path form as JSON — what a front end that compiles with
+// the reference's default flags has in hand, for tests that marshal it into kexc_il_program's block form.
+int kexc_dump_words(const char* source, size_t source_len, const char* source_name, int regex, char** json, size_t* json_len) {
+  try {
+    std::string name = source_name ? source_name : "<memory>";
+    std::vector<std::pair<kexc::WordSST, int>> ws;
+    if (regex) {
+      kexc::RProg rp = kexc::parseRegexProgram(std::string(source, source_len), name);
+      ws.push_back({kexc::determinizeWords(kexc::oracleTransducer(kexc::constructTransducer(rp, rp.pipeline[0], false))), -1});
+    } else {
+      kexc::RProg rp = kexc::desugar(kexc::parseKleenex(std::string(source, source_len), name));
+      for (int start : rp.pipeline) {
+        const bool acts = kexc::stageHasActions(rp, start);
+        ws.push_back({kexc::determinizeWords(kexc::constructTransducer(rp, start, acts)), acts ? (int)rp.regnames.size() : -1});
+      }
+    }
+    std::ostringstream o;
+    auto bytes = [&](const std::string& b) { o << "["; for (size_t i = 0; i < b.size(); ++i) o << (i ? "," : "") << (int)(unsigned char)b[i]; o << "]"; };
+    o << "[";
+    for (size_t si = 0; si < ws.size(); ++si) {
+      const kexc::WordSST& w = ws[si].first;
+      o << (si ? "," : "") << "{\"init\":" << w.init << ",\"action_regs\":" << ws[si].second << ",\"init_path\":[";
+      for (size_t l = 0; l < w.init_path.size(); ++l) { o << (l ? "," : ""); bytes(w.init_path[l]); }
+      o << "],\"states\":[";
+      for (size_t q = 0; q < w.states.size(); ++q) {
+        const auto& st = w.states[q];
+        o << (q ? "," : "") << "{\"nleaves\":" << st.nleaves << ",\"final_leaf\":" << st.final_leaf << ",\"edges\":[";
+        for (size_t k = 0; k < st.edges.size(); ++k) {
+          const auto& e = st.edges[k];
+          o << (k ? "," : "") << "{\"to\":" << e.to << ",\"word\":[";
+          for (size_t i = 0; i < e.word.size(); ++i) {   // each predicate as 32 bytes, bit b of the little-endian set = byte b
+            o << (i ? "," : "") << "[";
+            for (int x = 0; x < 32; ++x) o << (x ? "," : "") << (int)((e.word[i].w[x >> 3] >> (8 * (x & 7))) & 0xFF);
+            o << "]";
+          }
+          o << "],\"path\":[";
+          for (size_t l = 0; l < e.path.size(); ++l) {
+            o << (l ? "," : "") << "{\"parent\":" << e.path[l].parent << ",\"steps\":[";
+            for (size_t i = 0; i < e.path[l].steps.size(); ++i) { o << (i ? "," : "") << "[" << (e.path[l].steps[i].copy ? 1 : 0) << ","; bytes(e.path[l].steps[i].bytes); o << "]"; }
+            o << "]}";
+          }
+          o << "]}";
+        }
+        o << "]}";
+      }
+      o << "]}";
+    }
+    o << "]";
+    std::string txt = o.str();
+    *json = dupBytes(txt.data(), txt.size());
+    *json_len = txt.size();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 // Regex flavour (`.re` / `.rx` / `--re`): the bit-coder — kexc.hs:46-48 → generateOracleSSTs → compileCoder.
 int kexc_compile_regex(const char* regex, size_t regex_len, const char* source_name, int opt_level,
                        unsigned char** blob, size_t* blob_len) {
@@ -219,6 +297,59 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
     for (uint32_t pi = 0; pi < pl->nprograms; ++pi) {
       const kexc_il_program& P = pl->programs[pi];
       auto bad = [&](const std::string& what) { throw CompileError("program " + std::to_string(pi) + ": " + what); };
+      if (P.ntests) {
+        // block form (--la=true): tests are words of predicates.  The annotation alone defines the function: unroll it
+        // over the leaves into single-symbol steps and build the tables from that (kexc.h: leafGraph); the blocks'
+        // register updates say the same thing a second time and are not read.
+        if (!P.nstates || P.nstates >= 0xFFFF || P.init_state >= P.nstates || !P.maxleaves || P.maxleaves > 254) bad("state/leaf counts out of range");
+        if (!P.nleaves || !P.final_leaf || !P.pconst_off || !P.init_const || !P.test_block || !P.test_target || !P.test_len || !P.test_preds || !P.test_back ||
+            (P.npconsts && P.pconst_off[P.npconsts] && !P.pconst_pool)) bad("missing table");
+        std::vector<std::string> pc;
+        for (uint32_t c = 0; c < P.npconsts; ++c) {
+          if (P.pconst_off[c + 1] < P.pconst_off[c]) bad("path constant offsets out of order");
+          pc.emplace_back((const char*)P.pconst_pool + P.pconst_off[c], P.pconst_off[c + 1] - P.pconst_off[c]);
+        }
+        WordSST w;
+        w.states.resize(P.nstates); w.init = (int)P.init_state;
+        for (uint32_t q = 0; q < P.nstates; ++q) {
+          if (P.nleaves[q] == 0 || P.nleaves[q] > P.maxleaves || (P.final_leaf[q] != 0xFF && P.final_leaf[q] >= P.nleaves[q])) bad("leaf counts out of range");
+          w.states[q].nleaves = P.nleaves[q]; w.states[q].final_leaf = P.final_leaf[q] == 0xFF ? -1 : (int)P.final_leaf[q];
+        }
+        for (uint32_t l = 0; l < P.nleaves[P.init_state]; ++l) {
+          if (P.init_const[l] >= P.npconsts) bad("initial constant out of range");
+          w.init_path.push_back(pc[P.init_const[l]]);
+        }
+        size_t row = 0;
+        for (uint32_t k = 0; k < P.ntests; ++k) {
+          const uint32_t q = P.test_block[k], to = P.test_target[k], n = P.test_len[k];
+          if (q >= P.nstates || to >= P.nstates || n == 0 || n > 255) bad("test out of range");
+          WordEdge e; e.to = (int)to;
+          for (uint32_t i = 0; i < n; ++i) {
+            ByteSet p; memcpy(p.w, P.test_preds + 32 * (row + i), 32);
+            if (p.empty()) bad("empty predicate in a test");
+            e.word.push_back(p);
+          }
+          for (uint32_t l = 0; l < P.nleaves[to]; ++l) {
+            WordPath wp; wp.steps.resize(n);
+            for (uint32_t i = 0; i < n; ++i) {
+              const uint32_t v = P.test_back[(row + i) * P.maxleaves + l];
+              if (v == 0xFFFFFFFFu || (v >> 9) >= P.npconsts) bad("backward entry out of range");
+              if (i == 0) { wp.parent = (int)(v & 0xFF); if ((uint32_t)wp.parent >= P.nleaves[q]) bad("backward entry out of range"); }
+              wp.steps[i].copy = (v >> 8) & 1; wp.steps[i].bytes = pc[v >> 9];
+            }
+            e.path.push_back(std::move(wp));
+          }
+          w.states[q].edges.push_back(std::move(e));
+          row += n;
+        }
+        SST sst = determinize(leafGraph(w));
+        optimizeSST(sst, 3);
+        StageTables t = lower(sst, sst);
+        if (P.has_actions && P.action_regs > KXP_MAX_ACTION_REGS) bad("too many action registers (at most " + std::to_string(KXP_MAX_ACTION_REGS) + ")");
+        t.act_regs = P.has_actions ? (int)P.action_regs : -1;
+        stages.push_back(std::move(t));
+        continue;
+      }
       if (!P.nstates || P.nstates >= 0xFFFF || !P.nclasses || P.nclasses > 256 || P.init_state >= P.nstates) bad("state/class counts out of range");
       if (!P.maxleaves || P.maxleaves > 254) bad("maxleaves out of range");
       if (!P.class_of || !P.delta || !P.action || !P.final_action || !P.action_off || !P.const_off || !P.back_row || !P.nleaves || !P.final_leaf ||

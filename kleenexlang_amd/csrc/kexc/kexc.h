@@ -126,7 +126,8 @@ struct Atom {  // SymbolicSST.hs:52-56
   int var = 0;          // VAR
   std::string bytes;    // CONST
   int func = 0;         // FUNC: 0 = copy next[0] (CopyArg), 1 = CopyConst []
-  bool operator==(const Atom& o) const { return kind == o.kind && var == o.var && bytes == o.bytes && func == o.func; }
+  int sym = 0;          // FUNC: which symbol of a multi-symbol test it reads (`inj i`, Determinization.hs:224-226)
+  bool operator==(const Atom& o) const { return kind == o.kind && var == o.var && bytes == o.bytes && func == o.func && sym == o.sym; }
 };
 using UpdateString = std::vector<Atom>;
 struct PathStep { int parent; bool copy; std::string bytes; };  // per new leaf: origin leaf + appended output
@@ -147,6 +148,22 @@ struct SST {
   std::vector<std::string> init_path;  // output accumulated on each leaf of the initial closure
 };
 SST determinize(const FST& f);             // sstFromFST … singletonMode=True  (--la=false)
+
+// The path form of the lookahead machine (sstFromFST … singletonMode=False, `--la=true`, the reference's default): a
+// block tests WORDS of predicates — the single symbols of the coarsest partition plus the longest deterministic prefix
+// of every leaf (prefixTests / ldp, SymbolicFST.hs:264-312) — and a leaf of the target extends a leaf of the source by
+// one (copy?, constant) step per symbol of the word (consumeTreeMany, Determinization.hs:213-228).
+struct WordStep { bool copy = false; std::string bytes; };
+struct WordPath { int parent = 0; std::vector<WordStep> steps; };
+struct WordEdge { std::vector<ByteSet> word; int to = 0; std::vector<WordPath> path; };   // path: one per leaf of `to`
+struct WordState { std::vector<WordEdge> edges; int nleaves = 0, final_leaf = -1; };
+struct WordSST { std::vector<WordState> states; int init = 0; std::vector<std::string> init_path; };
+WordSST determinizeWords(const FST& f);
+// The same function as a prioritized single-symbol transducer over (state, leaf) nodes: every (test, target leaf) becomes
+// an alternative of its parent leaf's node — a chain of one symbol edge per symbol of the word — longer words first
+// (the blocks try them first: a leaf killed by a short test dies within the longer word anyway), then in leaf order.
+// determinize() of it is a table machine (one symbol per step) that writes what the lookahead machine writes.
+FST leafGraph(const WordSST& w);
 int optimizeSST(SST& s, int level);        // SymbolicSST.optimize; returns #iterations
 
 // ------------------------------------------------------------ table form
@@ -180,7 +197,7 @@ std::vector<uint8_t> writeBlob(const std::vector<StageTables>& stages, const std
 std::string emitC(const std::vector<StageTables>& stages, const std::string& info);
 
 struct Options {
-  int opt = 3; bool la = true; bool act = true; bool quiet = false;
+  int opt = 3; bool la = false; bool act = true; bool quiet = false;
   std::string out, srcout, cc = "cc", backend = "hip", blobout;
   int copt = 3;
   bool regex = false;          // regex flavour: the bit-coder (kexc.hs:46-48, compileCoder Commands.hs:246-275)

@@ -119,7 +119,7 @@ int main(int argc, char** argv) {
       if (!in) { std::cerr << file << ": openFile: does not exist (No such file or directory)\n"; return 1; }
       ss << in.rdbuf();
     }
-    if (!o.quiet && !simulate) std::cout << "Compile: " << srcname << (o.regex ? " (regex flavour: bit-coder; --la=false semantics)\n" : " (direct mode; --la=false semantics)\n");
+    if (!o.quiet && !simulate) std::cout << "Compile: " << srcname << (o.regex ? " (regex flavour: bit-coder; " : " (direct mode; ") << (o.la ? "--la=true: word tests unrolled over the path tree's leaves)\n" : "--la=false)\n");
     if (simulate) {
       // Commands.hs:277-323: stdin → the pipeline → stdout, whichever simulator is asked for — here every type is the
       // compiled program on the HIP engine (their outputs are equal by the reference's own invariant, Tests/Regression.hs:45-53)

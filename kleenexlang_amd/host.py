@@ -171,6 +171,44 @@ def compile_source(source, name="<memory>", opt=3):
         lib.kexc_free(blob)
 
 
+def compile_flags(source, name="<memory>", opt=3, la=False, regex=False):
+    """``kexc compile --opt N --la=BOOL`` (regex=True: ``--re``) → KXP blob.  la=True builds the reference's lookahead machine
+    (word tests) first and the tables from its path form (include/kexc_api.h::kexc_compile_flags)."""
+    lib = load_compiler()
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    blob = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    lib.kexc_compile_flags.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    rc = lib.kexc_compile_flags(source, len(source), name.encode(), opt, 1 if la else 0, 1 if regex else 0, ctypes.byref(blob), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return ctypes.string_at(blob, n.value)
+    finally:
+        lib.kexc_free(blob)
+
+
+def dump_words(source, name="<memory>", regex=False):
+    """JSON-decoded lookahead machines (``--la=true``) of a program's stages in path form (test support)."""
+    import json
+    lib = load_compiler()
+    if isinstance(source, str):
+        source = source.encode("utf-8")
+    txt = ctypes.c_void_p()
+    n = ctypes.c_size_t()
+    lib.kexc_dump_words.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                    ctypes.POINTER(ctypes.c_size_t)]
+    rc = lib.kexc_dump_words(source, len(source), name.encode(), 1 if regex else 0, ctypes.byref(txt), ctypes.byref(n))
+    if rc:
+        raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
+    try:
+        return json.loads(ctypes.string_at(txt, n.value).decode("utf-8"))
+    finally:
+        lib.kexc_free(txt)
+
+
 def emit_c(source, name="<memory>", opt=3):
     """``--backend=c``: reference-shaped C text for the CPU baseline."""
     lib = load_compiler()
@@ -260,7 +298,9 @@ class KexcIlProgram(ctypes.Structure):
                 ("nleaves", _u8p), ("final_leaf", _u8p), ("back", _u32p),
                 ("npconsts", ctypes.c_uint32), ("pconst_off", _u32p), ("pconst_pool", _u8p), ("init_const", _u32p),
                 ("has_actions", ctypes.c_uint32), ("action_regs", ctypes.c_uint32),
-                ("ntables", ctypes.c_uint32), ("tbl_width", _u32p), ("tbl_data", _u8p), ("back_table", _u32p)]
+                ("ntables", ctypes.c_uint32), ("tbl_width", _u32p), ("tbl_data", _u8p), ("back_table", _u32p),
+                ("ntests", ctypes.c_uint32), ("test_block", _u32p), ("test_target", _u32p), ("test_len", _u32p),
+                ("test_preds", _u8p), ("test_back", _u32p)]
 
 
 class KexcPipeline(ctypes.Structure):
@@ -277,7 +317,22 @@ def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bi
     kinds = {"class_of": np.uint8, "delta": np.uint16, "action": np.uint32, "final_action": np.uint32, "action_off": np.uint32, "ops": np.uint32,
              "const_off": np.uint32, "const_pool": np.uint8, "back_row": np.uint32, "nleaves": np.uint8, "final_leaf": np.uint8,
              "back": np.uint32, "pconst_off": np.uint32, "pconst_pool": np.uint8, "init_const": np.uint32}
+    def ptr(a, dt):
+        return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8 if dt == np.uint8 else ctypes.c_uint16 if dt == np.uint16 else ctypes.c_uint32))
     for st, P in zip(structs, programs):
+        st.ntests = int(P.get("ntests", 0))
+        if st.ntests:      # block form (--la=true): only the annotation travels, the class tables stay NULL
+            for k in ("nstates", "init_state", "maxleaves", "npconsts"):
+                setattr(st, k, int(P[k]))
+            st.has_actions, st.action_regs = int(P.get("has_actions", 0)), int(P.get("action_regs", 0))
+            for k, dt in (("nleaves", np.uint8), ("final_leaf", np.uint8), ("pconst_off", np.uint32), ("pconst_pool", np.uint8), ("init_const", np.uint32),
+                          ("test_block", np.uint32), ("test_target", np.uint32), ("test_len", np.uint32), ("test_preds", np.uint8), ("test_back", np.uint32)):
+                a = np.ascontiguousarray(np.asarray(P[k], dtype=dt).ravel())
+                if a.size == 0:
+                    a = np.zeros(1, dtype=dt)
+                keep.append(a)
+                setattr(st, k, ptr(a, dt))
+            continue
         for k in ("nstates", "nclasses", "init_state", "nregs", "nactions", "nconsts", "maxleaves", "nback", "npconsts"):
             setattr(st, k, int(P[k]))
         st.has_actions, st.action_regs = int(P.get("has_actions", 0)), int(P.get("action_regs", 0))

@@ -10,11 +10,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // kinds
 enum { RD32_RAND, RD32_HOT, RD8_ASCII, WR8_STRIDE80, WR8_STRIDE80_M3, WR8_STRIDE80_M10, WR32_UNAL80, WR32_AL80, RD32_UNAL_RAND,
-       RD64_RAND, WR32_M11_RAND, WR128_CONTIG, RD16_RAND, WR8_JIT, WR32_UNAL_JIT, RD32_UNAL_STRIDE64, RD128_CONTIG, WR64_UNAL_JIT, NKINDS };
+       RD64_RAND, WR32_M11_RAND, WR128_CONTIG, RD16_RAND, WR8_JIT, WR32_UNAL_JIT, RD32_UNAL_STRIDE64, RD128_CONTIG, WR64_UNAL_JIT,
+       WR8_COL, WR8_P132, WR8_P132_JIT, WR32_COL, RD32_COL, WR8_P132_M3, WR8_RANDOM, NKINDS };
 static const char* kname[] = {"ds_read_b32 random 13.5KB", "ds_read_b32 50 hot entries", "ds_read_u8 ascii cls", "ds_write_b8 lane*80+k",
   "ds_write_b8 lane*80+k 1/3 lanes", "ds_write_b8 lane*80+k 1/10 lanes", "ds_write_b32 unaligned lane*80+4k+1", "ds_write_b32 aligned lane*80+4k",
   "ds_read_b32 unaligned random", "ds_read_b64 random", "ds_write_b32 1/11 lanes random", "ds_write_b128 contiguous", "ds_read_u16 random",
-  "ds_write_b8 jitter(70..90)*lane", "ds_write_b32 unaligned jitter", "ds_read_b32 unaligned lane*64+k (input gather)", "ds_read_b128 contiguous", "ds_write_b64 unaligned jitter"};
+  "ds_write_b8 jitter(70..90)*lane", "ds_write_b32 unaligned jitter", "ds_read_b32 unaligned lane*64+k (input gather)", "ds_read_b128 contiguous", "ds_write_b64 unaligned jitter",
+  "ds_write_b8 column (bank = lane)", "ds_write_b8 lane*132+k", "ds_write_b8 lane*132+drift(0..23)+k", "ds_write_b32 column (bank = lane)", "ds_read_b32 column (bank = lane)",
+  "ds_write_b8 lane*132+drift+k 1/3 lanes", "ds_write_b8 random 6 KB"};
 
 __device__ __forceinline__ uint32_t lcg(uint32_t& s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
@@ -50,6 +53,13 @@ __global__ void k(uint32_t* out, uint64_t* ticks) {
       case RD32_UNAL_STRIDE64: a[j] = wbase + lane * 64 + 4 * j + (lane * 5 & 3); break;
       case RD128_CONTIG: a[j] = wbase + lane * 16 + (j & 3) * 1024; break;
       case WR64_UNAL_JIT: a[j] = wbase + jit + 8 * j + (lane & 3); break;
+      case WR8_COL: a[j] = wbase + lane * 4 + (j >> 2) * 256 + (j & 3); break;
+      case WR8_P132: a[j] = wbase + lane * 132 + j; break;
+      case WR8_P132_JIT: a[j] = wbase + lane * 132 + (lane * 2654435761u >> 8) % 24 + j; break;
+      case WR8_P132_M3: a[j] = wbase + lane * 132 + (lane * 2654435761u >> 8) % 24 + j; active = lane % 3 == 0; break;
+      case WR32_COL: a[j] = wbase + lane * 4 + j * 256; break;
+      case RD32_COL: a[j] = wbase + lane * 4 + j * 256; break;
+      case WR8_RANDOM: a[j] = wbase + r % 6144; break;
     }
   }
   uint32_t acc = 0, v = lane * 0x01010101u;
@@ -57,7 +67,7 @@ __global__ void k(uint32_t* out, uint64_t* ticks) {
   if (active) {
     for (int it = 0; it < REPS; ++it) {
       uint32_t r0, r1, r2, r3, r4, r5, r6, r7;
-      if constexpr (KIND == RD32_RAND || KIND == RD32_HOT || KIND == RD32_UNAL_RAND || KIND == RD32_UNAL_STRIDE64) {
+      if constexpr (KIND == RD32_RAND || KIND == RD32_HOT || KIND == RD32_UNAL_RAND || KIND == RD32_UNAL_STRIDE64 || KIND == RD32_COL) {
         asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %9\n ds_read_b32 %2, %10\n ds_read_b32 %3, %11\n ds_read_b32 %4, %12\n ds_read_b32 %5, %13\n ds_read_b32 %6, %14\n ds_read_b32 %7, %15\n s_waitcnt lgkmcnt(0)"
                      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
                      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
@@ -83,7 +93,7 @@ __global__ void k(uint32_t* out, uint64_t* ticks) {
         asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %5\n ds_read_b128 %2, %6\n ds_read_b128 %3, %7\n s_waitcnt lgkmcnt(0)"
                      : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
         acc += q0.x ^ q1.y ^ q2.z ^ q3.w;
-      } else if constexpr (KIND == WR8_STRIDE80 || KIND == WR8_STRIDE80_M3 || KIND == WR8_STRIDE80_M10 || KIND == WR8_JIT) {
+      } else if constexpr (KIND == WR8_STRIDE80 || KIND == WR8_STRIDE80_M3 || KIND == WR8_STRIDE80_M10 || KIND == WR8_JIT || KIND == WR8_COL || KIND == WR8_P132 || KIND == WR8_P132_JIT || KIND == WR8_P132_M3 || KIND == WR8_RANDOM) {
         asm volatile("ds_write_b8 %0, %8\n ds_write_b8 %1, %8\n ds_write_b8 %2, %8\n ds_write_b8 %3, %8\n ds_write_b8 %4, %8\n ds_write_b8 %5, %8\n ds_write_b8 %6, %8\n ds_write_b8 %7, %8\n s_waitcnt lgkmcnt(0)"
                      :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(v) : "memory");
       } else if constexpr (KIND == WR128_CONTIG) {
@@ -109,7 +119,7 @@ __global__ void k(uint32_t* out, uint64_t* ticks) {
 template <int KIND>
 void run(int waves, uint32_t* d_out, uint64_t* d_ticks) {
   const int nops = (KIND == WR128_CONTIG || KIND == RD128_CONTIG) ? 4 : 8;
-  size_t lds = 32768 + 16 * 6144 + 1024;
+  size_t lds = 32768 + 16 * 6144 + 4096;
   hipFuncSetAttribute((const void*)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(waves * 64), lds, 0, d_out, d_ticks);

@@ -274,8 +274,12 @@ def test_lookahead_tables_on_the_engine(prog):
     try:
         assert p.run_host(data) == oracle.run(blob_of(prog), data, path_form=True)
         bad = data[:300000] + b"\x01\x02" + data[300000:400000]
-        with pytest.raises(MatchError) as e:
-            p.run_host(bad)
-        assert ("fail", e.value.pos) == outcome(blob_of(prog), bad, True)
+        want = outcome(blob_of(prog), bad, True)
+        if isinstance(want, tuple):
+            with pytest.raises(MatchError) as e:
+                p.run_host(bad)
+            assert ("fail", e.value.pos) == want
+        else:   # (add_commas copies what is not a digit: nothing to reject)
+            assert p.run_host(bad) == want
     finally:
         p.close()

@@ -30,12 +30,18 @@
  *     u32 pback[nstates*nclasses]            backward-row id of the transition
  *     u8  nleaves[nstates] ; u8 fin_leaf[nstates]   (0xFF = not final)
  *     u32 back[nback*maxleaves]              parent | copy<<8 | pconst<<9 ; 0xFFFFFFFF dead
+ *                                            (stages with symbol tables: pconst < 2^15, bits 24-31 = table+1, 0 = none)
  *     u32 pconst_off[npconsts+1] ; u8 pconstpool[]
  *     u32 init_const[maxleaves]              pconst per leaf of q0's closure
  *     u32 sync_next[nsync*nclasses] ; u32 sync_state[nsync]
+ *     if (actions & KXP_STAGE_HAS_TABLES): u32 ntables ; u8 table[ntables][256]
  *
- * Register actions (`r@t`, `!r`, `[r <- …]`, `[r += …]`; Kleenex/Actions.hs:28-38).  `actions` = 0: the stage's output is
- * final.  `actions` = 1 | nregs << 8: the stage's output is a TOKEN STREAM that an action interpreter replays on a stack of
+ * Symbol tables (round 3) — the IL's AppendTblI (IL.hs:44, SSTCompiler/Classes.hs:102-125, C.hs:421-430): output =
+ * table[symbol], one byte.  Register form: micro-op KXP_OP_APPEND_TBL dst, table.  Path form: a back entry whose copy bit
+ * is set and whose table field is t+1 appends table[t][input byte] instead of the input byte.
+ *
+ * Register actions (`r@t`, `!r`, `[r <- …]`, `[r += …]`; Kleenex/Actions.hs:28-38).  `actions` bit 0 clear: the stage's output is
+ * final.  `actions` = 1 | nregs << 8 (| KXP_STAGE_HAS_TABLES): the stage's output is a TOKEN STREAM that an action interpreter replays on a stack of
  * buffers and nregs registers before it leaves the stage (action post-pass) — escape byte 0xFF:
  *     FF FF   the byte 0xFF            FF 00   Push: a new empty buffer on the stack
  *     FF 01 r Pop r: register r := top buffer, popped            FF 02 r Write r: top buffer ++= register r; r := empty
@@ -58,6 +64,10 @@
 #define KXP_OP_APPEND_CONST 1u /* AppendI dst, const    */
 #define KXP_OP_APPEND_SYM 2u   /* AppendSymI dst, 0     */
 #define KXP_OP_CONCAT 3u       /* ConcatI dst, src      */
+#define KXP_OP_APPEND_TBL 4u   /* AppendTblI dst, table: appends table[symbol] */
+
+#define KXP_STAGE_HAS_TABLES 2u /* bit of the stage header's `actions` word: a symbol-table section follows sync_state */
+#define KXP_MAX_TABLES 254u
 
 /* sync_state values for non-singleton subsets */
 #define KXP_SYNC_MULTI 0xFFFFFFFFu   /* several states still possible */

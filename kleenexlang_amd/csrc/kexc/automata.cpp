@@ -140,8 +140,9 @@ FST constructTransducer(const RProg& rp, int start, bool tokens) {
 // fixed-width code of the symbol's index in p (CodeArg p), every other symbol edge outputs nothing; `epseps`: the k-th of
 // n > 1 ε-alternatives outputs the fixed-width code of k, a lone ε-edge nothing.  Digits are base 256 (Frontend.hs:117),
 // so a code is one byte up to 256 alternatives (Util/Coding.hs:13-19,66-73: width = least w with 256^w >= n, big-endian).
-// The engine's tables have no symbol-indexed output function, so CodeArg p leaves as |p| single-symbol edges, each
-// followed by a lone ε-edge carrying that symbol's code — the same relation, symbol for symbol.
+// CodeArg p is a TABLE ATOM (round 3): the edge keeps its predicate and carries the table "symbol -> its index in p"
+// (one byte: |p| <= 256), which the SST, the blob and the engine's output stage know as output = table[symbol]
+// (AppendTblI, IL.hs:44; C.hs:421-430) — the program keeps its few byte classes instead of one per member of p.
 FST oracleTransducer(const FST& f) {
   auto code = [](int n, int k) {
     int w = 0; long long cap = 1;
@@ -153,7 +154,6 @@ FST oracleTransducer(const FST& f) {
   FST o;
   o.nstates = f.nstates; o.init = f.init; o.is_final = f.is_final;
   o.eps.resize((size_t)f.nstates); o.sym.resize((size_t)f.nstates);
-  auto fresh = [&]() { o.eps.emplace_back(); o.sym.emplace_back(); o.is_final.push_back(0); return o.nstates++; };
   for (int q = 0; q < f.nstates; ++q) {
     const auto& es = f.eps[(size_t)q];
     for (size_t k = 0; k < es.size(); ++k)
@@ -161,13 +161,13 @@ FST oracleTransducer(const FST& f) {
     for (const auto& e : f.sym[(size_t)q]) {
       const int n = e.pred.size();
       if (!e.copy || n <= 1) { o.sym[(size_t)q].push_back({e.pred, false, e.to}); continue; }
+      std::array<uint8_t, 256> t{};
       int idx = 0;
-      for (int x = 0; x < 256; ++x) {
-        if (!e.pred.has(x)) continue;
-        const int s = fresh();
-        o.sym[(size_t)q].push_back({ByteSet::single(x), false, s});
-        o.eps[(size_t)s].push_back({code(n, idx++), e.to});
-      }
+      for (int x = 0; x < 256; ++x) if (e.pred.has(x)) t[(size_t)x] = (uint8_t)idx++;
+      size_t k = 0;
+      while (k < o.tables.size() && o.tables[k] != t) ++k;
+      if (k == o.tables.size()) o.tables.push_back(t);
+      o.sym[(size_t)q].push_back({e.pred, true, e.to, (int)k});
     }
   }
   return o;
@@ -263,7 +263,7 @@ struct Determinizer {
       if (!hit) return std::nullopt;
       if (vis.count(hit->to)) return std::nullopt;
       vis.insert(hit->to);
-      Tree n; n.st = hit->to; n.tag = tag; n.out = {funcAtom(hit->copy ? 0 : 1)}; n.out[0].sym = idx;
+      Tree n; n.st = hit->to; n.tag = tag; n.out = {funcAtom(hit->copy ? 0 : 1)}; n.out[0].sym = idx; n.out[0].tbl = hit->copy ? hit->tbl : -1;
       return n;
     });
     if (r) reduceTree(*r);
@@ -403,7 +403,7 @@ SST determinize(const FST& f) {
           seen_new = true;
           if (at.kind == Atom::FUNC) {
             if (!ps.bytes.empty() || ps.copy) throw CompileError("internal: symbol function not first on a path");
-            ps.copy = at.func == 0;
+            ps.copy = at.func == 0; ps.tbl = at.tbl;
           } else ps.bytes += at.bytes;
         }
         edge.path.push_back(ps);
@@ -429,7 +429,7 @@ SST determinize(const FST& f) {
         for (auto at : kv.second) {
           if (at.kind == Atom::FUNC) {
             if (at.func == 1) at = constAtom("");
-            else if (single) at = constAtom(std::string(1, char(p.first())));
+            else if (single) at = constAtom(std::string(1, char(at.tbl >= 0 ? f.tables[(size_t)at.tbl][(size_t)p.first()] : p.first())));
           }
           if (at.kind == Atom::CONST) {
             if (at.bytes.empty()) continue;
@@ -456,6 +456,7 @@ SST determinize(const FST& f) {
     st.final_upd = std::move(norm);
   }
   sst.nregs = (int)varIds.size();
+  sst.tables = f.tables;
   return sst;
 }
 
@@ -580,7 +581,7 @@ WordSST determinizeWords(const FST& f) {
           if (a.kind == Atom::VAR) { if (at >= 0) throw CompileError("internal: register after new output on a path"); continue; }
           if (a.kind == Atom::FUNC) {
             if (a.sym != at + 1) throw CompileError("internal: symbols of a test out of order on a path");
-            at = a.sym; wp.steps[(size_t)at].copy = a.func == 0;
+            at = a.sym; wp.steps[(size_t)at].copy = a.func == 0; wp.steps[(size_t)at].tbl = a.tbl;
           } else if (at < 0) { if (!a.bytes.empty()) throw CompileError("internal: output before the first symbol of a test"); }
           else wp.steps[(size_t)at].bytes += a.bytes;
         }
@@ -593,6 +594,7 @@ WordSST determinizeWords(const FST& f) {
       w.states[sid].edges.push_back(std::move(edge));
     }
   }
+  w.tables = f.tables;
   return w;
 }
 
@@ -600,6 +602,7 @@ FST leafGraph(const WordSST& w) {
   using Word = std::vector<ByteSet>;
   using Cons = std::set<Word>;   // words the input must NOT start with from here: longer tests that would have fired instead
   FST g;
+  g.tables = w.tables;
   auto fresh = [&]() { g.eps.emplace_back(); g.sym.emplace_back(); g.is_final.push_back(0); return g.nstates++; };
   if (w.init < 0 || (size_t)w.init >= w.states.size() || (int)w.init_path.size() != w.states[(size_t)w.init].nleaves)
     throw CompileError("initial state and initial path constants disagree");
@@ -636,7 +639,7 @@ FST leafGraph(const WordSST& w) {
   // machine stays one leaf of the table machine; where alternatives do not agree (overlapping predicates, different copy
   // flags: no machine of the reference's does that) they are read apart, in order.
   struct Alt { const WordEdge* e; int lt; Cons c; };
-  struct Group { ByteSet pred; bool copy; std::vector<Alt> alts; };
+  struct Group { ByteSet pred; bool copy; int tbl; std::vector<Alt> alts; };
   std::function<void(int, const std::vector<Alt>&, size_t, bool)> fill;
   auto after = [&](int m, const std::vector<Alt>& alts, size_t i) {   // m: symbol i has been read; what follows it, in order
     for (size_t k = 0; k < alts.size();) {
@@ -655,13 +658,14 @@ FST leafGraph(const WordSST& w) {
     for (const Alt& a : alts) {
       const ByteSet& p = a.e->word[i];
       const bool c = a.e->path[(size_t)a.lt].steps[i].copy;
+      const int tb = c ? a.e->path[(size_t)a.lt].steps[i].tbl : -1;
       Group* hit = nullptr; bool clash = false;
       for (auto& gr : runs.back()) {
-        if (gr.pred == p) { if (gr.copy == c) hit = &gr; else clash = true; }
+        if (gr.pred == p) { if (gr.copy == c && gr.tbl == tb) hit = &gr; else clash = true; }
         else if (!(gr.pred & p).empty()) clash = true;
       }
       if (clash) { runs.emplace_back(); hit = nullptr; }
-      if (hit) hit->alts.push_back(a); else runs.back().push_back(Group{p, c, {a}});
+      if (hit) hit->alts.push_back(a); else runs.back().push_back(Group{p, c, tb, {a}});
     }
     auto reader = [&](int r, const std::vector<Group>& run) {
       for (const Group& gr : run) {
@@ -693,7 +697,7 @@ FST leafGraph(const WordSST& w) {
           }
           if (live.empty()) continue;
           const int m = fresh();
-          g.sym[(size_t)r].push_back({part, gr.copy, m});
+          g.sym[(size_t)r].push_back({part, gr.copy, m, gr.tbl});
           after(m, live, i);
         }
       }

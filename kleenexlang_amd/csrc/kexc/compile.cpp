@@ -140,8 +140,14 @@ static void fstJson(std::ostringstream& o, const kexc::FST& f, bool toks) {
         int e = b; while (e + 1 < 256 && f.sym[q][k].pred.has(e + 1)) ++e;
         o << (fr ? "" : ",") << "[" << b << "," << e << "]"; fr = false; b = e + 1;
       }
-      o << "]," << (f.sym[q][k].copy ? 1 : 0) << "," << f.sym[q][k].to << "]";
+      o << "]," << (f.sym[q][k].copy ? 1 : 0) << "," << f.sym[q][k].to << "," << f.sym[q][k].tbl << "]";
     }
+    o << "]";
+  }
+  o << "],\"tables\":[";
+  for (size_t k = 0; k < f.tables.size(); ++k) {
+    o << (k ? "," : "") << "[";
+    for (int b = 0; b < 256; ++b) o << (b ? "," : "") << (int)f.tables[k][(size_t)b];
     o << "]";
   }
   o << "]}";
@@ -225,12 +231,18 @@ int kexc_dump_words(const char* source, size_t source_len, const char* source_na
           o << "],\"path\":[";
           for (size_t l = 0; l < e.path.size(); ++l) {
             o << (l ? "," : "") << "{\"parent\":" << e.path[l].parent << ",\"steps\":[";
-            for (size_t i = 0; i < e.path[l].steps.size(); ++i) { o << (i ? "," : "") << "[" << (e.path[l].steps[i].copy ? 1 : 0) << ","; bytes(e.path[l].steps[i].bytes); o << "]"; }
+            for (size_t i = 0; i < e.path[l].steps.size(); ++i) { o << (i ? "," : "") << "[" << (e.path[l].steps[i].copy ? 1 : 0) << ","; bytes(e.path[l].steps[i].bytes); o << "," << e.path[l].steps[i].tbl << "]"; }
             o << "]}";
           }
           o << "]}";
         }
         o << "]}";
+      }
+      o << "],\"tables\":[";
+      for (size_t k = 0; k < w.tables.size(); ++k) {
+        o << (k ? "," : "") << "[";
+        for (int b = 0; b < 256; ++b) o << (b ? "," : "") << (int)w.tables[k][(size_t)b];
+        o << "]";
       }
       o << "]}";
     }
@@ -399,8 +411,15 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       for (uint32_t q = 0; q < P.nstates; ++q)
         if (t.final_act[q] != 0xFFFFFFFFu && t.final_act[q] < P.nactions)
           for (auto& m : t.actions[t.final_act[q]]) if (m.op == 4) bad("AppendTblI in a final action (no symbol to index with)");
-      if (uses_tables) {
-        // AppendTblI → AppendI: refine the byte classes until every table is constant on each class, then give each
+      bool native_tables = uses_tables && !getenv("KEXC_LOWER_TABLES");
+      for (uint32_t k = 0; k < P.ntables; ++k) native_tables = native_tables && P.tbl_width[k] == 1;
+      for (uint32_t e : t.back) native_tables = native_tables && (e == 0xFFFFFFFFu || (e >> 9) < (1u << 15));
+      if (native_tables && P.ntables <= KXP_MAX_TABLES) {
+        // one-byte tables stay TABLE ATOMS (round 3): micro-op 4 as it is, the path entry copies through its table
+        for (uint32_t k = 0; k < P.ntables; ++k) { std::array<uint8_t, 256> tb; memcpy(tb.data(), P.tbl_data + tbl_at[k], 256); t.tables.push_back(tb); }
+        for (size_t i = 0; i < btab.size(); ++i) if (btab[i] != 0xFFFFFFFFu) t.back[i] |= 0x100u | ((btab[i] + 1) << 24);
+      } else if (uses_tables) {
+        // AppendTblI → AppendI (tables of wider digits): refine the byte classes until every table is constant on each class, then give each
         // (state, class) its own copy of the action / backward row with the table entries written out as constants
         for (size_t i = 0; i < sc; ++i) if (t.delta[i] != 0xFFFF && (t.act[i] >= P.nactions || t.pback[i] >= P.nback)) bad("transition out of range");
         std::map<std::string, int> sig2cls;
@@ -482,7 +501,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
         if ((t.final_act[q] == 0xFFFFFFFFu) != (P.final_leaf[q] == 0xFF)) bad("final action and final leaf disagree");
       }
       t.nleaves.assign(P.nleaves, P.nleaves + P.nstates); t.fin_leaf.assign(P.final_leaf, P.final_leaf + P.nstates);
-      for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || (e >> 9) >= t.pconsts.size())) bad("backward entry out of range");
+      for (uint32_t e : t.back) if (e != 0xFFFFFFFFu && ((e & 0xFF) >= P.maxleaves || ((e >> 9) & (t.tables.empty() ? 0x7FFFFFu : 0x7FFFu)) >= t.pconsts.size())) bad("backward entry out of range");
       t.init_const.assign(P.init_const, P.init_const + P.maxleaves);
       for (uint32_t v : t.init_const) if (v >= P.npconsts) bad("initial constant out of range");
       if (P.has_actions && P.action_regs > KXP_MAX_ACTION_REGS) bad("too many action registers (at most " + std::to_string(KXP_MAX_ACTION_REGS) + ")");

@@ -46,7 +46,22 @@ std::string emitC(const std::vector<StageTables>& stages, const std::string& inf
   for (auto& t : stages) if (t.act_regs >= 0) throw CompileError("--backend=c prints direct-mode programs only (this one has register actions)");
   std::ostringstream o;
   o << "\n#define NUM_PHASES " << stages.size() << "\n#define BUFFER_UNIT_T uint8_t\n#include \"crt.c\"\n";
-  o << "/* no tables */\n";
+  {   // prettyTableDecl (C.hs:412-430): one array per phase that has tables
+    bool any = false;
+    for (size_t ph = 0; ph < stages.size(); ++ph) {
+      auto& t = stages[ph];
+      if (t.tables.empty()) continue;
+      any = true;
+      o << "const uint8_t tbl" << ph + 1 << "[" << t.tables.size() << "][256] =\n{";
+      for (size_t k = 0; k < t.tables.size(); ++k) {
+        o << (k ? ",\n{" : "{");
+        for (int b = 0; b < 256; ++b) { char buf[8]; snprintf(buf, sizeof buf, "0x%x", t.tables[k][(size_t)b]); o << (b ? "," : "") << buf; }
+        o << "}";
+      }
+      o << "};\n";
+    }
+    if (!any) o << "/* no tables */\n";
+  }
   int maxregs = 0;
   for (auto& t : stages) maxregs = std::max(maxregs, t.nregs);
   for (int r = 0; r < maxregs; ++r) o << "buffer_t buf_" << r << ";\n";
@@ -83,6 +98,10 @@ std::string emitC(const std::vector<StageTables>& stages, const std::string& inf
           }
           case KXP_OP_APPEND_SYM:
             if (stream) b << "outputconst(next[0],8);\n"; else b << "append(&buf_" << m.dst << ",next[0],8);\n";
+            break;
+          case KXP_OP_APPEND_TBL:   // prettyAppendTbl (C.hs:228-252)
+            if (stream) b << "outputconst(tbl" << P << "[" << m.arg << "][next[0]],8);\n";
+            else b << "append(&buf_" << m.dst << ",tbl" << P << "[" << m.arg << "][next[0]],8);\n";
             break;
           case KXP_OP_CONCAT:
             if (stream) b << "output(&buf_" << m.arg << ");\n"; else b << "concat(&buf_" << m.dst << ",&buf_" << m.arg << ");\n";

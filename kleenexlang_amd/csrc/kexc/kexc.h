@@ -15,6 +15,7 @@
 // blob for the HIP engine (see kxp_format.h); `--backend=c` prints C in the
 // reference's shape for the CPU baseline.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -109,7 +110,9 @@ struct FST {  // SymbolicFST.hs:49-55; states are ints after enumerateStates
   std::vector<char> is_final;
   // per state: ordered ε-edges (output bytes, target) — or symbol edges (pred, copy?, target)
   struct Eps { std::string out; int to; };
-  struct Sym { ByteSet pred; bool copy; int to; };
+  // tbl >= 0 (with copy): the symbol leaves through tables[tbl] — output = table[symbol], one byte (AppendTblI, IL.hs:44)
+  struct Sym { ByteSet pred; bool copy; int to; int tbl = -1; };
+  std::vector<std::array<uint8_t, 256>> tables;
   std::vector<std::vector<Eps>> eps;
   std::vector<std::vector<Sym>> sym;
 };
@@ -127,10 +130,11 @@ struct Atom {  // SymbolicSST.hs:52-56
   std::string bytes;    // CONST
   int func = 0;         // FUNC: 0 = copy next[0] (CopyArg), 1 = CopyConst []
   int sym = 0;          // FUNC: which symbol of a multi-symbol test it reads (`inj i`, Determinization.hs:224-226)
-  bool operator==(const Atom& o) const { return kind == o.kind && var == o.var && bytes == o.bytes && func == o.func && sym == o.sym; }
+  int tbl = -1;         // FUNC 0: >= 0 = the symbol leaves through that table of the transducer (CodeArg / AppendTblI)
+  bool operator==(const Atom& o) const { return kind == o.kind && var == o.var && bytes == o.bytes && func == o.func && sym == o.sym && tbl == o.tbl; }
 };
 using UpdateString = std::vector<Atom>;
-struct PathStep { int parent; bool copy; std::string bytes; };  // per new leaf: origin leaf + appended output
+struct PathStep { int parent; bool copy; std::string bytes; int tbl = -1; };  // per new leaf: origin leaf + appended output
 struct SSTEdge {
   ByteSet pred; int to;
   std::map<int, UpdateString> upd;   // register update (parallel assignment)
@@ -146,6 +150,7 @@ struct SSTState {
 struct SST {
   std::vector<SSTState> states; int init = 0; int nregs = 0;
   std::vector<std::string> init_path;  // output accumulated on each leaf of the initial closure
+  std::vector<std::array<uint8_t, 256>> tables;   // the transducer's symbol tables (FST::tables)
 };
 SST determinize(const FST& f);             // sstFromFST … singletonMode=True  (--la=false)
 
@@ -153,11 +158,11 @@ SST determinize(const FST& f);             // sstFromFST … singletonMode=True 
 // block tests WORDS of predicates — the single symbols of the coarsest partition plus the longest deterministic prefix
 // of every leaf (prefixTests / ldp, SymbolicFST.hs:264-312) — and a leaf of the target extends a leaf of the source by
 // one (copy?, constant) step per symbol of the word (consumeTreeMany, Determinization.hs:213-228).
-struct WordStep { bool copy = false; std::string bytes; };
+struct WordStep { bool copy = false; std::string bytes; int tbl = -1; };
 struct WordPath { int parent = 0; std::vector<WordStep> steps; };
 struct WordEdge { std::vector<ByteSet> word; int to = 0; std::vector<WordPath> path; };   // path: one per leaf of `to`
 struct WordState { std::vector<WordEdge> edges; int nleaves = 0, final_leaf = -1; };
-struct WordSST { std::vector<WordState> states; int init = 0; std::vector<std::string> init_path; };
+struct WordSST { std::vector<WordState> states; int init = 0; std::vector<std::string> init_path; std::vector<std::array<uint8_t, 256>> tables; };
 WordSST determinizeWords(const FST& f);
 // The same function as a prioritized single-symbol transducer over (state, leaf) nodes: every (test, target leaf) becomes
 // an alternative of its parent leaf's node — a chain of one symbol edge per symbol of the word — longer words first
@@ -180,7 +185,8 @@ struct StageTables {
   int maxleaves = 0;
   std::vector<uint32_t> pback;        // [nstates*nclasses] backward-row id
   std::vector<uint8_t> nleaves, fin_leaf;
-  std::vector<uint32_t> back;         // [nback*maxleaves]: parent | copy<<8 | pconst<<9 ; ~0u = dead
+  std::vector<uint32_t> back;         // [nback*maxleaves]: parent | copy<<8 | pconst<<9 | (table+1)<<24 ; ~0u = dead
+  std::vector<std::array<uint8_t, 256>> tables;   // symbol tables (KXP_OP_APPEND_TBL / the table field of a back entry)
   std::vector<std::string> pconsts;
   std::vector<uint32_t> init_const;   // [maxleaves] pconst id per leaf of q0
   // synchronising automaton over state subsets (all states → …)

@@ -53,6 +53,7 @@ struct Lowerer {
       const Atom& a = us[i];
       if (a.kind == Atom::VAR) ops.push_back({KXP_OP_CONCAT, (uint16_t)var, (uint32_t)a.var});
       else if (a.kind == Atom::CONST) ops.push_back({KXP_OP_APPEND_CONST, (uint16_t)var, constId(a.bytes)});
+      else if (a.func == 0 && a.tbl >= 0) ops.push_back({KXP_OP_APPEND_TBL, (uint16_t)var, (uint32_t)a.tbl});   // AppendTblI (IL.hs:44)
       else if (a.func == 0) ops.push_back({KXP_OP_APPEND_SYM, (uint16_t)var, 0});
     }
   }
@@ -108,6 +109,8 @@ StageTables lower(const SST& s, const SST&) {
   StageTables t;
   size_t n = s.states.size();
   t.nstates = (int)n; t.q0 = s.init;
+  t.tables = s.tables;
+  if (t.tables.size() > 254) throw CompileError("more than 254 symbol tables");
   // global byte classes: coarsest partition refining every predicate of every state
   {
     std::set<ByteSet> preds;
@@ -182,8 +185,10 @@ StageTables lower(const SST& s, const SST&) {
       if ((int)e.path.size() != s.states[e.to].nleaves) throw CompileError("internal: path form leaf count mismatch");
       for (size_t j = 0; j < e.path.size(); ++j) {
         uint32_t pc = pconstId(e.path[j].bytes);
-        if (pc >= (1u << 23)) throw CompileError("too many path constants");
-        row[j] = (uint32_t)e.path[j].parent | (e.path[j].copy ? 0x100u : 0u) | (pc << 9);
+        if (pc >= (t.tables.empty() ? 1u << 23 : 1u << 15)) throw CompileError("too many path constants");
+        const int tb = e.path[j].copy ? e.path[j].tbl : -1;
+        if (tb >= (int)t.tables.size()) throw CompileError("internal: symbol table out of range");
+        row[j] = (uint32_t)e.path[j].parent | (e.path[j].copy ? 0x100u : 0u) | (pc << 9) | ((uint32_t)(tb + 1) << 24);
       }
       auto it = bmap.find(row);
       if (it == bmap.end()) { it = bmap.emplace(row, (uint32_t)bmap.size()).first; t.back.insert(t.back.end(), row.begin(), row.end()); }
@@ -235,7 +240,7 @@ std::vector<uint8_t> writeBlob(const std::vector<StageTables>& stages, const std
     w.u32(KXP_STAGE_MAGIC); w.u32(t.nstates); w.u32(t.nclasses); w.u32(t.q0); w.u32(t.nregs);
     w.u32((uint32_t)t.actions.size()); w.u32((uint32_t)nops); w.u32((uint32_t)t.consts.size()); w.u32((uint32_t)cpl);
     w.u32(t.maxleaves); w.u32(nback); w.u32((uint32_t)t.pconsts.size()); w.u32((uint32_t)pcpl);
-    w.u32(nsync); w.u32(t.sync_complete ? 1 : 0); w.u32(t.act_regs >= 0 ? 1u | ((uint32_t)t.act_regs << 8) : 0u);
+    w.u32(nsync); w.u32(t.sync_complete ? 1 : 0); w.u32((t.act_regs >= 0 ? 1u | ((uint32_t)t.act_regs << 8) : 0u) | (t.tables.empty() ? 0u : KXP_STAGE_HAS_TABLES));
     w.raw(t.cls, 256);
     for (auto v : t.delta) w.u16(v);
     w.pad();
@@ -254,6 +259,7 @@ std::vector<uint8_t> writeBlob(const std::vector<StageTables>& stages, const std
     for (auto v : t.init_const) w.u32(v);
     for (auto v : t.sync_next) w.u32(v);
     for (auto v : t.sync_state) w.u32(v);
+    if (!t.tables.empty()) { w.u32((uint32_t)t.tables.size()); for (auto& tb : t.tables) w.raw(tb.data(), 256); }
   }
   return w.b;
 }

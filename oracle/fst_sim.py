@@ -49,9 +49,11 @@ def run_stage(fst, data):
     for b in data:
         stepped = []
         for acc, q in paths:
-            for ranges, copy, t in sym[q]:
+            for edge in sym[q]:
+                ranges, copy, t = edge[:3]
+                tbl = edge[3] if len(edge) > 3 else -1     # >= 0: the symbol leaves through that table (CodeArg / AppendTblI)
                 if any(lo <= b <= hi for lo, hi in ranges):
-                    stepped.append((acc + (bytes([b]) if copy else b""), t))
+                    stepped.append((acc + (bytes([fst["tables"][tbl][b] if tbl >= 0 else b]) if copy else b""), t))
         paths = _close(fst, stepped)
         if not paths:
             return None

@@ -43,6 +43,7 @@ typedef struct {
   const uint32_t *back, *pconst_off;
   const uint8_t* pconstpool;
   const uint32_t *init_const, *sync_next, *sync_state;
+  uint32_t ntables; const uint8_t* tables; /* [ntables][256]: AppendTblI's tables (IL.hs:44,84) */
 } stage_t;
 
 typedef struct { uint32_t nstages; stage_t* st; } prog_t;
@@ -84,6 +85,7 @@ static int parse_blob(const uint8_t* b, size_t len, prog_t* p) {
     t->init_const = (const uint32_t*)c; c += (size_t)t->maxleaves * 4;
     t->sync_next = (const uint32_t*)c; c += (size_t)t->nsync * t->nclasses * 4;
     t->sync_state = (const uint32_t*)c; c += (size_t)t->nsync * 4;
+    if (t->actions & KXP_STAGE_HAS_TABLES) { memcpy(&t->ntables, c, 4); c += 4; t->tables = c; c += (size_t)t->ntables * 256; }
     if ((size_t)(c - b) > len) return -1;
   }
   return 0;
@@ -128,10 +130,11 @@ static int run_stage_reg(const stage_t* t, const uint8_t* in, size_t n, buf_t* o
         case KXP_OP_RESET: d->len = 0; break;
         case KXP_OP_APPEND_CONST: buf_append(d, t->constpool + t->const_off[arg], t->const_off[arg + 1] - t->const_off[arg]); break;
         case KXP_OP_APPEND_SYM: buf_append(d, &in[count], 1); break;
+        case KXP_OP_APPEND_TBL: if (arg >= t->ntables) { rc = -3; break; } buf_append(d, &t->tables[(size_t)arg * 256 + in[count]], 1); break; /* C.hs:228-252 */
         case KXP_OP_CONCAT: buf_append(d, regs[arg].data, regs[arg].len); break; /* src keeps its value, crt.c:255-259 */
       }
     }
-    if (at_end) break;
+    if (at_end || rc) break;
     q = t->delta[(size_t)q * t->nclasses + t->cls[in[count]]];
     ++count; /* consume(1) */
   }
@@ -170,8 +173,9 @@ static int run_stage_path(const stage_t* t, const uint8_t* in, size_t n, buf_t* 
   for (i = 0; i < n; ++i) {
     uint32_t b = t->pback[(size_t)qs[i] * t->nclasses + t->cls[in[i]]];
     uint32_t e = t->back[(size_t)b * t->maxleaves + leaf[i + 1]];
-    if (e & 0x100) buf_append(out, &in[i], 1);
-    uint32_t c = e >> 9;
+    uint32_t tb = t->ntables ? e >> 24 : 0, c = t->ntables ? (e >> 9) & 0x7FFF : e >> 9;
+    if (tb > t->ntables) { rc = -3; goto done; }
+    if (e & 0x100) buf_append(out, tb ? &t->tables[(size_t)(tb - 1) * 256 + in[i]] : &in[i], 1);
     buf_append(out, t->pconstpool + t->pconst_off[c], t->pconst_off[c + 1] - t->pconst_off[c]);
   }
 done:

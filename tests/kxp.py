@@ -52,6 +52,11 @@ def parse(blob):
         s.init_const = take(np.uint32, s.maxleaves)
         s.sync_next = take(np.uint32, nsync * s.nclasses).reshape(nsync, s.nclasses)
         s.sync_state = take(np.uint32, nsync)
+        s.actions = h[15]
+        s.tables = None
+        if h[15] & 2:   # KXP_STAGE_HAS_TABLES: u32 ntables ; u8 table[ntables][256]
+            nt = int(take(np.uint32, 1)[0])
+            s.tables = take(np.uint8, nt * 256).reshape(nt, 256)
         stages.append(s)
     return stages
 
@@ -135,7 +140,9 @@ class CpuShard:
             q = self.states[i]
             e = int(t.back[t.pback[q, t.cls[self.d[i]]], leaf])
             assert e != 0xFFFFFFFF
-            piece = (bytes([self.d[i]]) if e & 0x100 else b"") + self._const(e >> 9)
+            tb, pc = (e >> 24, (e >> 9) & 0x7FFF) if t.tables is not None else (0, e >> 9)
+            sym = int(t.tables[tb - 1, self.d[i]]) if tb else self.d[i]
+            piece = (bytes([sym]) if e & 0x100 else b"") + self._const(pc)
             out.append(piece)
             leaf = e & 0xFF
         return leaf, b"".join(reversed(out))

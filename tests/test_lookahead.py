@@ -157,7 +157,7 @@ def marshal_words(w):
                 preds.extend(p)
                 row = [0xFFFFFFFF] * maxleaves
                 for leaf, path in enumerate(e["path"]):
-                    copy, bytes_ = path["steps"][i]
+                    copy, bytes_ = path["steps"][i][:2]
                     row[leaf] = (path["parent"] if i == 0 else 0) | copy << 8 | const(bytes_) << 9
                 back.extend(row)
     return dict(ntests=len(block), nstates=len(w["states"]), init_state=w["init"], maxleaves=maxleaves,

@@ -116,16 +116,27 @@ def coder_program_with_table():
         ntables=1, tbl_width=[1], tbl_data=table)
 
 
-def test_append_table_instruction_is_lowered_to_constants_per_refined_class(tmp_path):
-    """AppendTblI at the seam: classes are refined until the table is constant on each (a, b, c, d, the rest), the table
-    entries become constants, and the result is the program `kexc compile --re '[a-d]*'` builds itself."""
+@pytest.mark.parametrize("route", ["table atom", "constants"])
+def test_append_table_instruction_at_the_seam(tmp_path, monkeypatch, route):
+    """AppendTblI at the seam.  A table of one-byte entries stays a TABLE ATOM (kxp_format.h: micro-op 4, the table field
+    of a back entry): the program keeps its two classes.  Tables of wider entries — and any table under
+    KEXC_LOWER_TABLES=1 — take the older route: classes refined until the table is constant on each (a, b, c, d, the
+    rest), entries written out as constants.  Either way the function is the one `kexc compile --re '[a-d]*'` builds."""
     from kleenexlang_amd import host
     out = tmp_path / "coder.kxp"
+    if route == "constants":
+        monkeypatch.setenv("KEXC_LOWER_TABLES", "1")
     assert emit_pipeline([coder_program_with_table()], srcout=out) == 0
     blob = out.read_bytes()
+    host.validate_blob(blob)
     st = kxp.parse(blob)[0]
-    assert st.nclasses == 5 and len(set(int(st.cls[c]) for c in b"abcd")) == 4
+    if route == "constants":
+        assert st.nclasses == 5 and len(set(int(st.cls[c]) for c in b"abcd")) == 4 and st.tables is None
+    else:
+        assert st.nclasses == 2 and st.tables is not None and bytes(st.tables[0][ord("a"):ord("e")]) == bytes([0, 1, 2, 3])
+        assert any(int(w) >> 24 == 4 for w in st.ops[0::2])          # KXP_OP_APPEND_TBL survives in the register form
     own = host.compile_regex("[a-d]*")
+    assert kxp.parse(own)[0].nclasses == 2 and kxp.parse(own)[0].tables is not None
     for data in (b"", b"a", b"abcd", b"ddcbaabcd" * 50):
         want = bytes(x for ch in data for x in (0, ch - ord("a"))) + b"\x01"
         for pf in (False, True):
@@ -138,3 +149,72 @@ def test_append_table_instruction_is_lowered_to_constants_per_refined_class(tmp_
     bad = coder_program_with_table(); bad["final_action"] = [0]
     with pytest.raises(CompileError, match="final action"):
         emit_pipeline([bad], srcout=out)
+
+
+def mixed_copy_and_table_program():
+    """One block, one path: [a-d] leaves through a table (AppendTblI: upper case), [x-z] is copied as it is (AppendSymI),
+    ',' writes the constant ";" — plain copies beside table steps, the shape that needs a table id per path entry."""
+    cls = np.full(256, 3, dtype=np.uint8)
+    cls[ord("a"):ord("d") + 1] = 0
+    cls[ord("x"):ord("z") + 1] = 1
+    cls[ord(",")] = 2
+    table = np.zeros(256, dtype=np.uint8)
+    table[ord("a"):ord("d") + 1] = list(b"ABCD")
+    return dict(
+        nstates=1, nclasses=4, init_state=0, nregs=1, class_of=cls,
+        delta=[0, 0, 0, 0xFFFF], action=[0, 1, 2, 0], final_action=[3],
+        nactions=4, action_off=[0, 1, 2, 3, 3], ops=[(4 << 24) | 0, 0, (2 << 24) | 0, 0, (1 << 24) | 0, 0],
+        nconsts=1, const_off=[0, 1], const_pool=list(b";"),
+        maxleaves=1, nback=3, back_row=[0, 1, 2, 0], nleaves=[1], final_leaf=[0],
+        back=[0 | (0 << 8) | (0 << 9), 0 | (1 << 8) | (0 << 9), 0 | (0 << 8) | (1 << 9)], back_table=[0, 0xFFFFFFFF, 0xFFFFFFFF],
+        npconsts=2, pconst_off=[0, 0, 1], pconst_pool=list(b";"), init_const=[0],
+        ntables=1, tbl_width=[1], tbl_data=table)
+
+
+def mixed_expected(data):
+    return bytes(c - 32 if c in b"abcd" else (ord(";") if c == ord(",") else c) for c in data)
+
+
+def test_plain_copies_beside_table_steps(tmp_path):
+    out = tmp_path / "mixed.kxp"
+    assert emit_pipeline([mixed_copy_and_table_program()], srcout=out) == 0
+    blob = out.read_bytes()
+    from kleenexlang_amd import host
+    host.validate_blob(blob)
+    for data in (b"", b"abxd,zzca", b"xyz" * 100, b",,,"):
+        for pf in (False, True):
+            assert oracle.run(blob, data, path_form=pf) == mixed_expected(data), (data, pf)
+    with pytest.raises(oracle.OracleMatchError):
+        oracle.run(blob, b"abq")
+
+
+@pytest.mark.gpu
+def test_table_atoms_on_the_engine(tmp_path, monkeypatch):
+    """Symbol tables in the engine's output stage: per-entry table ids (plain copies beside table steps, GENERAL instances)
+    and the one-table form (the piece is translated once, fast instances), also from global memory (BIG)."""
+    import random
+    from kleenexlang_amd import host
+    out = tmp_path / "mixed.kxp"
+    assert emit_pipeline([mixed_copy_and_table_program()], srcout=out) == 0
+    mixed = out.read_bytes()
+    assert emit_pipeline([coder_program_with_table()], srcout=out) == 0
+    coder = out.read_bytes()
+    rnd = random.Random(5)
+    dm = bytes(rnd.choice(b"abcdxyz,") for _ in range(3 << 20))
+    dc = bytes(rnd.choice(b"abcd") for _ in range(3 << 20))
+    for env in ({}, {"KX_FORCE_BIG": "1"}, {"KX_FORCE_TBLMODE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for blob, data, want in ((mixed, dm, mixed_expected(dm)), (coder, dc, None)):
+            for seg in (0, 4096):
+                p = host.Program(blob, segment_bytes=seg)
+                try:
+                    for d in (data, data[:1000], b""):
+                        assert p.run_host(d) == (mixed_expected(d) if want is not None else oracle.run(blob, d)), (env, seg, len(d))
+                    with pytest.raises(host.MatchError) as e:
+                        p.run_host(data[:70000] + b"Q" + data[:10])
+                    assert e.value.pos == 70000
+                finally:
+                    p.close()
+        for k in env:
+            monkeypatch.delenv(k)

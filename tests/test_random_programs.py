@@ -66,11 +66,11 @@ def test_random_programs_failure_position_is_first_dead_prefix():
             # a live path exists for data[:pos] (the run got that far) …
             paths = fst_sim._close(fst, [(b"", fst["init"])])
             for b in data[:pos]:
-                paths = fst_sim._close(fst, [(a, t) for a, q in paths for rg, cp, t in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)])
+                paths = fst_sim._close(fst, [(a, t) for a, q in paths for rg, cp, t, *_ in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)])
             assert paths, (seed, data, pos)
             if pos < len(data):   # … and none survives the next symbol
                 b = data[pos]
-                nxt = [(a, t) for a, q in paths for rg, cp, t in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)]
+                nxt = [(a, t) for a, q in paths for rg, cp, t, *_ in fst["sym"][q] if any(lo <= b <= hi for lo, hi in rg)]
                 assert not fst_sim._close(fst, nxt), (seed, data, pos)
 
 

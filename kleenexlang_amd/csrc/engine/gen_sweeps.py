@@ -17,6 +17,11 @@ before doing the bookkeeping of the current step.
       31..0 from (leafB, oB); see the step description in kx_engine.hip (k_emit).  jb (SGPR, in/out) is
       the LDS address of the wave's next free job slot, jlim that of the last slot.
 
+  piece_sweep2i(...)
+      the same sweep for programs in the INLINE-CONSTANT entry layout (DevTables::inl: a one-byte constant rides in byte 2
+      of its entry): per step and chain one more address op and one more byte store, no job.  The cursors are kept one
+      byte low (o' = o - 1) so that both stores reach their byte with an offset field.
+
   piece_forward1 / piece_run1 / piece_walk1
       one-chain forms for k_backlen (whose two input pieces per trip leave no room for two chains) and
       k_forward: forward with / without recording the back rows, and the measuring backward walk.
@@ -64,7 +69,7 @@ def fwd2():
     return L
 
 
-def sweep2():
+def sweep2(inl=False):
     L = []
     ap = L.append
     row = lambda t: "%%[bo%d]" % (t >> 1)
@@ -81,7 +86,8 @@ def sweep2():
         cur, nxt = (31 - j) & 1, (32 - j) & 1
         # the two entry reads are the oldest operations in flight; behind them sit the previous step's two byte
         # stores (always) and job stores (sometimes): waiting for "all but two" never waits for less than the reads
-        ap("s_waitcnt lgkmcnt(%d)" % (0 if j == 31 else 2))
+        # (inl: four byte stores per step, so "all but four" is still no less than the reads)
+        ap("s_waitcnt lgkmcnt(%d)" % (0 if j == 31 else 4 if inl else 2))
         for ch in "AB":
             ap("v_and_b32 %%[leaf%s], 0x3fc, %%[e%s%d]" % (ch, ch, cur))
             if j > 0:
@@ -96,10 +102,15 @@ def sweep2():
                 ap("v_lshrrev_b32 %%[tw%s], 8, %%[w%d]" % (ch, t >> 2))
             src = "%%[tw%s]" % ch if by in (1, 3) else "%%[w%d]" % (t >> 2)
             wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            if inl:
+                # the inline constant is the LAST byte the step appends: address o' (cursor before the subtraction); byte 1 of
+                # an entry without one is negative (bit 15), which sign-extended into the address sends the store out of range
+                ap("v_or_b32_sdwa %%[ti%s], %s, sext(%s) %s src0_sel:DWORD src1_sel:BYTE_1" % (ch, o, e, SD))
+                ap("ds_write_b8_d16_hi %%[ti%s], %s" % (ch, e))
             ap("v_sub_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, e, SD))
             ap("v_cmp_gt_i32_sdwa %s, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % ("%[mA]" if ch == "A" else "vcc", e))
             ap("v_lshl_or_b32 %s, %s, 31, %s" % (e, e, o))
-            ap("%s %s, %s" % (wr, e, src))
+            ap("%s %s, %s%s" % (wr, e, src, " offset:1" if inl else ""))
         # constants of both chains in one store: lanes of the union take a slot each (wave-wide running count +
         # rank), chain A's job where there is one, else chain B's; the rare lane with both stores B's separately
         eA, aA, aB = "%%[eA%d]" % cur, "%%[aA%d]" % cur, "%%[aB%d]" % cur
@@ -268,6 +279,17 @@ def main():
             "uint32_t& jb, uint32_t jlim",
             "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv, mA, mU;",
             sweep2(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[mA] "=&s"(mA)', '[mU] "=&s"(mU)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
+                                                       '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
+            ['[jlim] "s"(jlim)'],
+            '"vcc", "scc", "memory"')
+    tmp = tmp + ["tiA", "tiB"]
+    emit_fn(out, "piece_sweep2i",
+            "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
+            "uint32_t& jb, uint32_t jlim",
+            "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv, mA, mU;",
+            sweep2(True),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[mA] "=&s"(mA)', '[mU] "=&s"(mU)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
                                                        '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +

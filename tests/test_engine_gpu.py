@@ -720,3 +720,37 @@ def test_action_mirrors_in_lds_fall_back_to_global_memory():
         for data in inputs:
             assert prog.run_host(data) == oracle.run(blob, data), (src[:40], len(data))
         prog.close()
+
+
+def test_inline_constant_layout(monkeypatch):
+    """One-byte constants ride in their path entries (DevTables::inl, piece_sweep2i): a program whose constants are mostly
+    one byte takes the layout by itself; KX_INL=1 forces it onto the workloads (few one-byte constants beside long ones, the
+    jobs still run); bytes >= 0x80 as inline constants (they look like jobs to the sweep); a constant on EVERY symbol with
+    longer ones between (staging rounds, oversize pieces); KX_INL=0 is the ordinary layout.  Engine = oracle throughout."""
+    rng = random.Random(23)
+    text = bytes(rng.choice(b"abcdefgh,\n") for _ in range(300000))
+    progs = ['main := (/[a-d]/ "1" | /[e-h]/ "\\xfe" | ~/,/ ";" | /\\n/ "<end of line>\\n")*\n',
+             'main := (/[a-h]/ "." | ~/,/ | ~/\\n/ "%s")*\n' % ("=" * 90),
+             'main := (~/[a-d]/ "x" | /[e-h,]/ | /\\n/ "\\x80\\x81")*\n']
+    for src in progs:
+        blob = blob_of(src)
+        for inl in ("", "0", "1"):
+            if inl:
+                monkeypatch.setenv("KX_INL", inl)
+            for data in [text[:1], text[:64], text[:4097], text]:
+                for seg in (64, 4096, 0):
+                    got, want = both(blob, data, segment_bytes=seg)
+                    assert got == want, (src[:30], inl, len(data), seg)
+            bad = text[:100000] + b"Z" + text[:50]
+            got, want = both(blob, bad)
+            assert got == want == ("fail", 100000)
+            monkeypatch.delenv("KX_INL", raising=False)
+    monkeypatch.setenv("KX_INL", "1")
+    for prog in ["apache_log", "csv2json", "iso_datetime_to_json", "thousand_sep"]:
+        data = workloads.generate(workloads.PROGRAM_INPUT[prog], 6 << 20, 31)
+        for seg in (0, 4096):
+            got, want = both(blob_of(prog), data, segment_bytes=seg)
+            assert got == want, (prog, seg)
+    monkeypatch.setenv("KX_EMIT_STG", "1024")   # tiny staging: rounds and pieces written straight to global memory
+    got, want = both(blob_of(progs[1]), text)
+    assert got == want

@@ -62,8 +62,10 @@ typedef struct kexc_il_program {
    * of tbl_width[arg] digits (bytes: progOutBits = 8).  Table t starts at tbl_data + 256 * (tbl_width[0] + … +
    * tbl_width[t-1]); the entry of symbol s lies at + s * tbl_width[t].  In the annotation, back_table[row*maxleaves + leaf]
    * names the table whose entry for the symbol read is appended on that path step BEFORE the path constant (0xFFFFFFFF =
-   * none; not together with the copy bit); NULL when ntables == 0.  The engine's tables hold no symbol-indexed output:
-   * kexc_emit_pipeline refines the byte classes until every table is constant on each class and turns op 4 into op 1. */
+   * none; not together with the copy bit); NULL when ntables == 0.  Tables of ONE-byte entries (every table the coder's
+   * CodeArg makes: |p| <= 256) stay table atoms — kxp_format.h: KXP_OP_APPEND_TBL, the table field of a back entry — and
+   * the engine's output stage looks the symbol up.  Tables of wider entries (or KEXC_LOWER_TABLES=1) are
+   * written out: the byte classes are refined until every table is constant on each class and op 4 becomes op 1. */
   uint32_t ntables; const uint32_t* tbl_width; const uint8_t* tbl_data; const uint32_t* back_table;
   /* Block form — `--la=true`, the reference's default.  A block then tests WORDS: `IfI (avail>=n && p_0(next[0]) && … &&
    * p_{n-1}(next[n-1])) (updates ++ [ConsumeI n, GotoI s])`, nested by common prefix, longer words first (prefixTests /

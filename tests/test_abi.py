@@ -58,8 +58,8 @@ def test_corrupt_and_truncated_blobs_are_refused_not_read_out_of_bounds():
     import struct
     import pytest
     from kleenexlang_amd import EngineError, compile_file, host
-    for name in ("flip_ab", "csv2json", "apache_log"):
-        blob = compile_file(name)
+    for name in ("flip_ab", "csv2json", "apache_log", "coder"):
+        blob = host.compile_regex("([a-c]*|[0-9]+)(,|;)?x*") if name == "coder" else compile_file(name)   # (coder: a symbol-table section)
         host.validate_blob(blob)                         # the real thing passes
         step = max(1, len(blob) // 400)
         for cut in list(range(0, 200)) + list(range(200, len(blob) - 1, step)):
@@ -96,6 +96,21 @@ def test_corrupt_and_truncated_blobs_are_refused_not_read_out_of_bounds():
         b = bytearray(blob); b[nl_off + st.q0] = 0
         with pytest.raises(EngineError, match="leaf count"):
             host.validate_blob(bytes(b))
+        if st.tables is not None:   # table field of a back entry: beyond the tables / on an entry that does not copy
+            nback = st.back.shape[0]
+            back_off = nl_off + 2 * pad4(st.nstates)
+            assert bytes(blob[back_off:back_off + 4 * nback * st.maxleaves]) == st.back.tobytes()
+            live = [i for i, e in enumerate(st.back.reshape(-1)) if e != 0xFFFFFFFF]
+            with_tb = [i for i in live if int(st.back.reshape(-1)[i]) >> 24]
+            assert with_tb
+            b = bytearray(blob); struct.pack_into("<I", b, back_off + 4 * with_tb[0], (int(st.back.reshape(-1)[with_tb[0]]) & 0xFFFFFF) | (len(st.tables) + 1) << 24)
+            with pytest.raises(EngineError, match="backward entry"):
+                host.validate_blob(bytes(b))
+            b = bytearray(blob); struct.pack_into("<I", b, back_off + 4 * with_tb[0], int(st.back.reshape(-1)[with_tb[0]]) & ~0x100)
+            with pytest.raises(EngineError, match="backward entry"):
+                host.validate_blob(bytes(b))
+            with pytest.raises(EngineError, match="symbol tables"):
+                host.validate_blob(blob[:len(blob) - 100])
         fin = [q for q in range(st.nstates) if st.fin_leaf[q] != 0xFF]
         if fin:
             b = bytearray(blob); b[nl_off + pad4(st.nstates) + fin[0]] = st.nleaves[fin[0]]

@@ -9,6 +9,9 @@ for f in ("gpu_pytest.txt", "kernel_stats.csv", "pmc_raw.json", "traffic.json", 
 for p in ("apache_log", "csv2json", "iso_datetime_to_json"):
     shutil.copy(os.path.join(G, "bench_%s.json" % p), os.path.join(P, "%s_bench_%s.json" % (TAG, p)))
 shutil.copy(os.path.join(G, "bench.json"), os.path.join(P, "%s_bench_under_rocprof.json" % TAG))
+for f, t in (("bench_thousand_sep.json", "%s_bench_thousand_sep.json" % TAG), ("coder_bench_csv_rows_4gib.json", "r03_coder_bench_csv_rows_4gib.json"),
+             ("actions_16m.json", "%s_actions_16m.json" % TAG), ("actions_1g.json", "%s_actions_1g.json" % TAG)):
+    if os.path.exists(os.path.join(G, f)) and os.path.getsize(os.path.join(G, f)): shutil.copy(os.path.join(G, f), os.path.join(P, t))
 sq = os.path.join(R, "gpurun_out", TAG + "_sq", "sq_counters.json")
 if os.path.exists(sq): shutil.copy(sq, os.path.join(P, "%s_sq_counters.json" % TAG))
 load = lambda n: json.loads(open(os.path.join(G, n)).read())
@@ -41,6 +44,12 @@ sw = open(os.path.join(G, "soak_windows.txt")).read().strip().splitlines()[-1] i
 out.append("GPU test suite of the same tree: `%s_gpu_pytest.txt` (%s); soak of this engine build: `%s_soak_engine.txt` (%s), `%s_soak_windows.txt` (%s).\n" % (TAG, pt, TAG, se, TAG, sw))
 out.append("SQ counters of this engine (2 GiB, one counter per pass): `%s_sq_counters.json`; iso_datetime_to_json: `r03_sq_counters_iso_datetime.json`.\n" % TAG)
 out.append("Round-3 experiments and their evidence: `r03x_info_pipeline_runs.txt`, `r03x_info_pipeline_sq_counters.json`, `r03_probe_stride_rw.txt` (`probes/stride_rw.hip`), `r03_path_stats.txt` (`path_stats.py`), "
-           "`r03_emit_constants_ablation.txt`, `r03_actions_bench.txt`, `r03_bench_big.json` (`big_bench.py`).\n")
+           "`r03_emit_constants_ablation.txt`, `r03_actions_bench.txt`, `r03_bench_big.json` (`big_bench.py`), `r03_bank_placement_experiment.txt` (`bank_model.py`, `bank_place.py`).\n")
+ex = lambda f: json.loads(open(os.path.join(G, f)).read()) if os.path.exists(os.path.join(G, f)) and os.path.getsize(os.path.join(G, f)) else None
+ts, cb, a1 = ex("bench_thousand_sep.json"), ex("coder_bench_csv_rows_4gib.json"), ex("actions_1g.json")
+if ts: out.append("Inline-constant layout: thousand_sep 10 GiB %.0f GB/s (`%s_bench_thousand_sep.json`, k_emit %.2f ms).\n" % (ts["value"], TAG, ts["kernels_ms"]["emit"]))
+if cb: out.append("Table atoms + inline constants: CSV-row coder over 4 GiB %.0f GB/s, k_emit %.2f ms, %d output bytes checked (`r03_coder_bench_csv_rows_4gib.json`).\n" % (cb["input_GBps"], cb["kernels_ms"]["emit"], cb["output_bytes_checked"]))
+if a1: out.append("Action post-pass at 1 GiB: swap_fields %.1f GB/s, long_lines %.1f GB/s (`%s_actions_1g.json`).\n" % (a1["swap_fields"]["input_MBps"] / 1e3, a1["long_lines"]["input_MBps"] / 1e3, TAG))
+
 open(os.path.join(P, "%s_summary.md" % TAG), "w").write("".join(out))
 print("".join(out))

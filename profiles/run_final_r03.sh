@@ -12,4 +12,6 @@ bash profiles/collect.sh $TAG > $O/collect.log 2>&1; tail -3 $O/collect.log
 bash profiles/collect_sq.sh ${TAG}_sq > $O/collect_sq.log 2>&1; tail -3 $O/collect_sq.log
 SOAK_LO=5000 SOAK_HI=6500 timeout 1500 python tests/soak/soak_engine.py > $O/soak_engine.txt 2>&1; tail -2 $O/soak_engine.txt
 timeout 1200 python tests/soak/soak_windows.py > $O/soak_windows.txt 2>&1; tail -1 $O/soak_windows.txt
+timeout 600 python bench.py --program thousand_sep --steps 10 --warmup 2 --no-cpu > $O/bench_thousand_sep.json 2>/dev/null; cut -c1-200 $O/bench_thousand_sep.json
+timeout 600 python profiles/coder_bench.py 4 2>/dev/null | tail -1 > $O/coder_bench_csv_rows_4gib.json; cut -c100-600 $O/coder_bench_csv_rows_4gib.json
 python profiles/actions_bench.py > $O/actions_16m.json 2>/dev/null; KX_BENCH_MIB=1024 python profiles/actions_bench.py > $O/actions_1g.json 2>/dev/null; tail -c 400 $O/actions_1g.json

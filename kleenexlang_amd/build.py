@@ -17,7 +17,7 @@ PKG = os.path.join(ROOT, "kleenexlang_amd")
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "_build")
 
-KEXC_SRCS = ["frontend.cpp", "automata.cpp", "lower.cpp", "emit_c.cpp", "compile.cpp"]
+KEXC_SRCS = ["frontend.cpp", "automata.cpp", "lower.cpp", "emit_c.cpp", "compile.cpp", "simulate.cpp"]
 CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-sign-compare"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -211,5 +211,7 @@ struct Options {
 };
 struct Compiled { std::vector<StageTables> stages; std::string info; std::vector<int> sst_states; };
 Compiled compileSource(const std::string& src, const std::string& srcname, const Options& o);
+// the reference's FST simulators on the CPU (simulate.cpp): 0 accepted, 1 rejected, 2 malformed action program
+int simulateFST(const std::string& src, const std::string& srcname, const Options& o, bool backtracking, const std::string& input, std::string& out);
 
 }  // namespace kexc

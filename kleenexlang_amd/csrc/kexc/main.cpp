@@ -120,9 +120,20 @@ int main(int argc, char** argv) {
       ss << in.rdbuf();
     }
     if (!o.quiet && !simulate) std::cout << "Compile: " << srcname << (o.regex ? " (regex flavour: bit-coder; " : " (direct mode; ") << (o.la ? "--la=true: word tests unrolled over the path tree's leaves)\n" : "--la=false)\n");
+    if (simulate && sim != "sst") {
+      // Commands.hs:277-302: the FST simulators run the nondeterministic transducers themselves, on the CPU, as the
+      // reference's do (simulate.cpp) — the language's user-visible oracle, independent of everything the compiler does after
+      // the transducer; `--sim sst` below is the compiled program on the HIP engine
+      std::string input((std::istreambuf_iterator<char>(std::cin)), std::istreambuf_iterator<char>()), output;
+      const int rc = simulateFST(ss.str(), srcname, o, sim == "backtrack", input, output);
+      if (rc == 1) { std::cerr << "Reject\n"; return 1; }
+      if (rc == 2) { std::cerr << "Malformed action program: non-singleton stack on termination\n"; return 1; }
+      std::cout.write(output.data(), (std::streamsize)output.size());
+      std::cout.flush();
+      return 0;
+    }
     if (simulate) {
-      // Commands.hs:277-323: stdin → the pipeline → stdout, whichever simulator is asked for — here every type is the
-      // compiled program on the HIP engine (their outputs are equal by the reference's own invariant, Tests/Regression.hs:45-53)
+      // Commands.hs:304-323 (`--sim sst`): stdin → the compiled pipeline → stdout on the HIP engine
       o.quiet = true;
       Compiled cs = compileSource(ss.str(), srcname, o);
       std::vector<uint8_t> sblob = writeBlob(cs.stages, cs.info);

@@ -667,9 +667,11 @@ def test_forward_walk_variants_agree(monkeypatch):
 
 
 def test_kexc_simulate_runs_the_program_on_the_engine(tmp_path):
-    """`kexc simulate` / `interpret` (stdin → pipeline → stdout, Commands.hs:277-323).  Every `--sim` type is
-    the compiled program on the HIP engine; rejections use the reference simulators' words ("Reject" for the FST
-    simulations, Commands.hs:285; SymbolicSST.hs:425-427 for `--sim sst`), exit code 1, nothing on stdout."""
+    """`kexc simulate` / `interpret` (stdin → pipeline → stdout, Commands.hs:277-323).  `--sim sst` is the
+    compiled program on the HIP engine; `lockstep` (the default) and `backtrack` are the reference's FST simulators on the CPU
+    (csrc/kexc/simulate.cpp, tests/test_simulators.py) — three routes, one output.  Rejections use the reference simulators'
+    words ("Reject" for the FST simulations, Commands.hs:285; SymbolicSST.hs:425-427 for `--sim sst`), exit code 1, nothing on
+    stdout."""
     import subprocess
     from kleenexlang_amd import build, program_path
     kexc = os.path.join(build.OUT, "kexc")

@@ -132,3 +132,28 @@ def test_reference_regex_sources_compile_as_coders_and_routes_agree():
                 accepted += 1
                 assert oracle.run(blob, data) == oracle.run(blob, data, path_form=True) == want, (name, data)
         assert accepted >= 2, name
+
+
+def test_table_atoms_through_the_c_backend_and_the_reference_runtime(tmp_path):
+    """A coder's `AppendTblI` printed the reference's way (`const uint8_t tbl1[n][256]`, `outputconst(tbl1[k][next[0]],8)`,
+    C.hs:228-252,412-430) and compiled against the reference's OWN crt/crt.c writes what the oracle writes for the blob —
+    the table atom of round 3 against the reference's runtime, register form and path form, with and without lookahead."""
+    import random
+    import subprocess
+    from kleenexlang_amd import build
+    kexc = os.path.join(build.OUT, "kexc")
+    rnd = random.Random(3)
+    cases = [("(([a-z]*|[0-9]+)(,|\\n))*", b"".join(rnd.choice([b"abc", b"", b"0042", b"z"]) + rnd.choice([b",", b"\n"]) for _ in range(3000))),
+             ("([^,\\n]*,)*[^,\\n]*\\n", b"ab,c,,\xff\x00zz,q\n"),
+             (".[^a]", b"\x00\xff")]
+    for regex, data in cases:
+        for la in ([], ["--la"]):
+            out = tmp_path / "coder_c"
+            r = subprocess.run([kexc, "compile", "--quiet", "--backend=c", "--crt-dir", os.path.join(REF, "crt"), *la, "--re", regex, "--out", str(out), "--srcout", str(tmp_path / "c.c")],
+                               stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+            assert b"tbl1[" in (tmp_path / "c.c").read_bytes()
+            got = subprocess.run([str(out)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            blob = host.compile_flags(regex, opt=3, la=bool(la), regex=True)
+            for pf in (False, True):
+                assert got.returncode == 0 and got.stdout == oracle.run(blob, data, path_form=pf), (regex, la, pf, got.stderr)

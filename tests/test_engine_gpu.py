@@ -415,6 +415,14 @@ def test_c_driver_shards_inside_one_process_and_in_the_binary(tmp_path):
         assert errs == [None] * world, errs
         assert b"".join(o[1] for o in outs) == want and all(o[2] == len(want) for o in outs)
         assert [o[0] for o in outs] == [sum(len(x[1]) for x in outs[:r]) for r in range(world)]
+    # the inline-constant layout (thousand_sep) and a coder's symbol tables (one table: translated per piece) across shards
+    from kleenexlang_amd import host
+    for blob_x, data_x in ((blob_of("thousand_sep"), workloads.generate("numbers", 2 << 20, 5)),
+                           (host.compile_regex("(([^,\\n]*),([^,\\n]*)\\n)*"), b"".join(b"ab%d,x%dyz\n" % (i, i * 7) for i in range(150000)))):
+        want_x = oracle.run(blob_x, data_x)
+        outs, errs = run_ranks(blob_x, data_x, 4)
+        assert errs == [None] * 4, errs
+        assert b"".join(o[1] for o in outs) == want_x
     # two stages: the second stage's shards are the first stage's output slices
     src2 = 'start: a >> b\na := (~/x/ "yy" | /[^x]/)*\nb := (~/yy/ "z" | /./)*\n'
     blob2 = blob_of(src2)

@@ -764,3 +764,33 @@ def test_inline_constant_layout(monkeypatch):
     monkeypatch.setenv("KX_EMIT_STG", "1024")   # tiny staging: rounds and pieces written straight to global memory
     got, want = both(blob_of(progs[1]), text)
     assert got == want
+
+
+def test_lane_replay_keeps_short_strings_in_registers(monkeypatch, capfd):
+    """k_actions_lanes (one lane per chunk) keeps frames and registers of at most 8 bytes in VGPRs and everything longer in its
+    arenas: fields of 0..20 bytes cross that line in both directions — a short register written into a long frame, a long one
+    into a short frame, frames pushed over a cached frame (nesting inside a line), empty fields, the byte FF."""
+    monkeypatch.setenv("KX_DEBUG", "1")
+    monkeypatch.setenv("KX_ACT_PAR_MIN", "20000")
+    monkeypatch.setenv("KX_ACT_CHUNK", "2048")
+    monkeypatch.setenv("KX_ACT_LANES", "1")
+    rnd = random.Random(77)
+    word = lambda lo, hi, abc: bytes(rnd.choice(abc) for _ in range(rnd.randrange(lo, hi)))
+    progs = [
+        # swap: both fields 0..20 bytes
+        ('main := (a@/[a-z\\xff]*/ ~/,/ b@/[0-9]*/ !b "," !a /\\n/)*\n', lambda: word(0, 21, b"abcxyz\xff") + b"," + word(0, 21, b"0123456789") + b"\n"),
+        # nesting inside the line: c is captured inside the frame of a, written back into it, a doubled
+        ('main := (a@(/[a-z]*/ c@/[0-9]*/ "<" !c !c ">") ~/;/ "[" !a "|" !a "]" /\\n/)*\n', lambda: word(0, 12, b"abc") + word(0, 12, b"0123") + b";\n"),
+        # a register appended to piecewise ([r += ...]) and written once per line
+        ('main := (line)*\nline := [r <- ""] (w@/[a-z]+/ [r += w "."] | ~/,/)* ~/;/ !r /\\n/\n', lambda: b"".join(word(1, 4, b"abc") + b"," for _ in range(rnd.randrange(0, 8))) + b";\n"),
+    ]
+    for src, line in progs:
+        data = b"".join(line() for _ in range(30000))
+        blob = blob_of(src)
+        want = oracle.run(blob, data)
+        p = Program(blob)
+        capfd.readouterr()
+        assert p.run_host(data) == want, src[:40]
+        err = capfd.readouterr().err
+        assert "one lane each" in err, err[-400:]
+        p.close()

@@ -774,6 +774,7 @@ def test_lane_replay_keeps_short_strings_in_registers(monkeypatch, capfd):
     monkeypatch.setenv("KX_ACT_PAR_MIN", "20000")
     monkeypatch.setenv("KX_ACT_CHUNK", "2048")
     monkeypatch.setenv("KX_ACT_LANES", "1")
+    monkeypatch.setenv("KX_ACT_PREFIX3_MIN", "64")     # (the three-step prefix of the block summaries, as on streams of GiBs)
     rnd = random.Random(77)
     word = lambda lo, hi, abc: bytes(rnd.choice(abc) for _ in range(rnd.randrange(lo, hi)))
     progs = [

@@ -45,7 +45,8 @@ static int usage() {
                "       kexc compile … FILE.re|FILE.rx --out BIN   |   kexc compile … --re 'REGEX' --out BIN\n"
                "                    (regex flavour: BIN writes the code of the greedy parse, one byte per choice)\n"
                "       kexc simulate|interpret [--sim lockstep|backtrack|sst] [--quiet] [--opt N] [--act[=BOOL]] FILE.kex  < in > out\n"
-               "                    (the program is compiled and run on the HIP engine; `interpret` = `simulate --quiet`)\n"
+               "                    (sst: the compiled program on the HIP engine; lockstep (default), backtrack: the FST simulators,\n"
+               "                     on the CPU; `interpret` = `simulate --quiet`)\n"
                "The reference's `visualize` subcommand is not part of this build.\n";
   return 1;
 }

@@ -68,6 +68,8 @@
 
 #define KXP_STAGE_HAS_TABLES 2u /* bit of the stage header's `actions` word: a symbol-table section follows sync_state */
 #define KXP_MAX_TABLES 254u
+#define KXP_ENGINE_TABLES 7u /* tables one stage may use beside each other on the engine (3-bit table field of a path entry);
+                                a compiler with more writes the smaller ones out as constants */
 
 /* sync_state values for non-singleton subsets */
 #define KXP_SYNC_MULTI 0xFFFFFFFFu   /* several states still possible */

@@ -22,6 +22,15 @@ before doing the bookkeeping of the current step.
       of its entry): per step and chain one more address op and one more byte store, no job.  The cursors are kept one
       byte low (o' = o - 1) so that both stores reach their byte with an offset field.
 
+  piece_sweep2j(bo, w, leafA, oA, leafB, oB, pA, pB)
+      the same sweep for programs in the JOB-STRIDE entry layout (DevTables::jl; round 4): byte 2 of an entry is 4 where a
+      constant follows and 0 elsewhere.  Every step stores its job word (cursor<<16 | entry address) at the lane's own
+      list pointer — unconditionally, no vote, no exec games, no scalar bookkeeping — and then advances the pointer by
+      byte 2: a step without a constant leaves garbage that the next step overwrites.  Chain A's list grows upward from
+      pA, chain B's downward from pB (both in the lane's private slot region).  Per step and chain 6 VALU + 1 LDS read
+      + 2 LDS writes against the vote-and-rank form's 6 VALU + ~5 VALU + ~6 SALU (measured: an instruction of ANY
+      kind costs a SIMD ≈ 4.1 cycles in these kernels).
+
   piece_forward1 / piece_run1 / piece_walk1
       one-chain forms for k_backlen (whose two input pieces per trip leave no room for two chains) and
       k_forward: forward with / without recording the back rows, and the measuring backward walk.
@@ -142,6 +151,46 @@ def sweep2(inl=False):
         ap("s_and_b64 %[mA], %[mA], vcc")
         ap("s_bcnt1_i32_b64 %[st], %[mA]")
         ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
+    ap("s_setprio 0")
+    return L
+
+
+def sweep2j():
+    """job-stride layout: lane-private job lists, unconditional job stores (see the module docstring)"""
+    L = []
+    ap = L.append
+    row = lambda t: "%%[bo%d]" % (t >> 1)
+    wsel = lambda t: "WORD_%d" % (t & 1)
+    base = {"A": 32, "B": 0}
+    ap("s_setprio 3")
+    for ch in "AB":
+        t = base[ch] + 31
+        ap("v_add_u32_sdwa %%[a%s0], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, row(t), ch, SD, wsel(t)))
+        ap("ds_read_b32 %%[e%s0], %%[a%s0]" % (ch, ch))
+    for j in range(31, -1, -1):
+        cur, nxt = (31 - j) & 1, (32 - j) & 1
+        # in flight, oldest first: the two entry reads, then the previous step's four stores (job + byte, per chain)
+        ap("s_waitcnt lgkmcnt(%d)" % (0 if j == 31 else 4))
+        for ch in "AB":
+            ap("v_and_b32 %%[leaf%s], 0x3fc, %%[e%s%d]" % (ch, ch, cur))
+            if j > 0:
+                t = base[ch] + j - 1
+                ap("v_add_u32_sdwa %%[a%s%d], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, nxt, row(t), ch, SD, wsel(t)))
+                ap("ds_read_b32 %%[e%s%d], %%[a%s%d]" % (ch, nxt, ch, nxt))
+        for ch in "AB":
+            t = base[ch] + j
+            e, o, a, p_ = "%%[e%s%d]" % (ch, cur), "%%[o%s]" % ch, "%%[a%s%d]" % (ch, cur), "%%[p%s]" % ch
+            by = t & 3
+            if by == 3:
+                ap("v_lshrrev_b32 %%[tw%s], 8, %%[w%d]" % (ch, t >> 2))
+            src = "%%[tw%s]" % ch if by in (1, 3) else "%%[w%d]" % (t >> 2)
+            wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            ap("v_sub_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, e, SD))
+            ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
+            ap("ds_write_b32 %s, %s" % (p_, a))
+            ap("%s %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_2" % ("v_add_u32_sdwa" if ch == "A" else "v_sub_u32_sdwa", p_, p_, e, SD))
+            ap("v_lshl_or_b32 %s, %s, 31, %s" % (e, e, o))
+            ap("%s %s, %s" % (wr, e, src))
     ap("s_setprio 0")
     return L
 
@@ -284,6 +333,16 @@ def main():
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
             ['[jlim] "s"(jlim)'],
             '"vcc", "scc", "memory"')
+    tmpj = ["eA0", "eA1", "eB0", "eB1", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
+    emit_fn(out, "piece_sweep2j",
+            "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
+            "uint32_t& pA, uint32_t& pB",
+            "uint32_t " + ", ".join(tmpj) + ";",
+            sweep2j(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmpj] + ['[leafA] "+v"(leafA)', '[oA] "+v"(oA)', '[leafB] "+v"(leafB)', '[oB] "+v"(oB)',
+                                                        '[pA] "+v"(pA)', '[pB] "+v"(pB)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
+            '"memory"')
     tmp = tmp + ["tiA", "tiB"]
     emit_fn(out, "piece_sweep2i",
             "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "

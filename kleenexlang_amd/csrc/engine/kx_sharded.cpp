@@ -184,9 +184,13 @@ int kx_group_allgather(void* ctx, const void* send, void* recv, size_t bytes) {
 void kx_group_abort(kx_group* g) { if (g) g->abort(); }
 
 // ------------------------------------------------------------------------------------ the driver
-// records of the three exchanges
-struct FwdMsg { uint32_t synced, end_state; uint64_t head_len, fail_pos, n; uint64_t fixed; };   // 40 bytes
-struct BwdMsg { uint32_t constant, nleaves; uint8_t start_leaf[KX_MAX_LEAVES]; uint64_t pad; };  // 272 bytes
+// records of the three exchanges.  Every record carries the sender's STATUS: a rank whose local step failed (out of memory, a HIP
+// error, a bad leaf) still takes part in the next exchange and says so there, so that every rank leaves the collective with an
+// error instead of waiting in an all-gather for a peer that has already returned.  The return code is therefore
+// collective: the failing rank returns its own code and message, the others KX_E_IO naming the lowest failing rank.
+struct FwdMsg { uint32_t synced, end_state; uint64_t head_len, fail_pos, n; uint32_t fixed, status; };   // 40 bytes
+struct BwdMsg { uint32_t constant, nleaves; uint8_t start_leaf[KX_MAX_LEAVES]; uint32_t status, pad; };  // 272 bytes
+struct LenMsg { uint64_t len; uint32_t status, pad; };                                                   // 16 bytes
 
 static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, void* ag_ctx, const void* d_in, size_t n,
                       void* d_out, size_t cap, kx_sharded_result* res, void* stream, void** res_alloc) {
@@ -209,35 +213,47 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
   struct FreeBufs { void** b; ~FreeBufs() { for (int i = 0; i < 2; ++i) if (b[i]) (void)hipFree(b[i]); } } free_bufs{stagebuf};
   std::vector<FwdMsg> fwd(world);
   std::vector<BwdMsg> bwd(world);
-  std::vector<uint64_t> lens(world);
+  std::vector<LenMsg> lens(world);
+  int err = 0;                 // this rank's first local failure (its message stays in the thread's error slot)
+  std::string err_msg;
+  auto local = [&](int rc) { if (rc && !err) { err = rc; err_msg = kx_last_error(); } return rc; };
+  // after an exchange: has any rank failed?  (every rank sees the same records, so every rank takes the same way out)
+  auto collective = [&](auto& recs) -> int {
+    for (int r = 0; r < world; ++r)
+      if (recs[r].status) {
+        res->boundary_ms = (float)boundary;
+        if (r == rank || err) return sErr(err ? err : KX_E_IO, err_msg.empty() ? "local failure" : err_msg);
+        return sErr(KX_E_IO, "rank " + std::to_string(r) + " of the sharded run failed (its own return code says why)");
+      }
+    return 0;
+  };
   int rc = 0;
   for (uint32_t st = 0; st < ns; ++st) {
     kx_shard* s = nullptr;
-    rc = kx_shard_begin(p, st, cur, curn, rank == 0, rank == world - 1, stream, &s);
-    if (rc) return rc;
+    local(kx_shard_begin(p, st, cur, curn, rank == 0, rank == world - 1, stream, &s));
     struct EndShard { kx_shard* s; kx_stats* acc; ~EndShard() {
+      if (!s) return;
       kx_stats ss; kx_shard_stats(s, &ss);
       for (int i = 0; i < KX_NKERNELS; ++i) { acc->kernel_ms[i] += ss.kernel_ms[i]; acc->total_ms += ss.kernel_ms[i]; }
       acc->unsynced_segments += ss.unsynced_segments;
       kx_shard_end(s); } } end_shard{s, &res->stats};
     // forward: the state entering every shard.  A shard whose end state depends on its start state (no synchronisation
     // point in the whole shard: never for the workloads) is fixed from the left in extra rounds.
-    kx_fwd_summary fs;
-    rc = kx_shard_forward(s, &fs);
-    if (rc) return rc;
+    kx_fwd_summary fs{};
+    if (!err) local(kx_shard_forward(s, &fs));
     bool fixed_me = false;
     for (;;) {
-      FwdMsg mine{fs.synced, fs.end_state, fs.head_len, fs.fail_pos, (uint64_t)curn, fixed_me ? 1ull : 0ull};
+      FwdMsg mine{fs.synced, fs.end_state, fs.head_len, fs.fail_pos, (uint64_t)curn, fixed_me ? 1u : 0u, err ? 1u : 0u};
       rc = gather(&mine, fwd.data(), sizeof(FwdMsg));
-      if (rc) return rc;
+      if (rc) return rc;                     // (the transport itself failed: nothing left to tell the peers with)
+      if ((rc = collective(fwd))) return rc;
       bool all = true;
       for (int r = 0; r < world; ++r) all = all && fwd[r].fixed;
       if (all) break;
       // ranks whose left neighbour's end state is known (synchronised or already fixed) fix their head now
       const bool left_known = rank == 0 || fwd[rank - 1].fixed || fwd[rank - 1].synced;
       if (!fixed_me && left_known) {
-        rc = kx_shard_fix_head(s, rank ? fwd[rank - 1].end_state : 0, &fs);
-        if (rc) return rc;
+        if (!err) local(kx_shard_fix_head(s, rank ? fwd[rank - 1].end_state : 0, &fs));
         fixed_me = true;
       }
     }
@@ -254,13 +270,14 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
       }
     }
     // backward: the leaf every shard ends in = the leaf its right neighbour starts in
-    kx_bwd_summary bs;
-    rc = kx_shard_backward(s, &bs);
-    if (rc) return rc;
+    kx_bwd_summary bs{};
+    if (!err) local(kx_shard_backward(s, &bs));
     {
       BwdMsg mine{}; mine.constant = bs.constant; mine.nleaves = bs.nleaves; memcpy(mine.start_leaf, bs.start_leaf, KX_MAX_LEAVES);
+      mine.status = err ? 1u : 0u;
       rc = gather(&mine, bwd.data(), sizeof(BwdMsg));
       if (rc) return rc;
+      if ((rc = collective(bwd))) return rc;
     }
     uint32_t end_leaf = 0;
     {
@@ -269,28 +286,36 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
       end_leaf = ends[rank];
     }
     uint64_t ol = 0;
-    rc = kx_shard_resolve(s, end_leaf, &ol);
-    if (rc) return rc;
-    rc = gather(&ol, lens.data(), sizeof(uint64_t));
-    if (rc) return rc;
-    uint64_t off = 0, total = 0;
-    for (int r = 0; r < world; ++r) { if (r < rank) off += lens[r]; total += lens[r]; }
-    // emit: the last stage into the caller's buffer, the others into a buffer that is the next stage's input
+    if (!err) local(kx_shard_resolve(s, end_leaf, &ol));
+    // emit: the last stage into the caller's buffer, the others into a buffer that is the next stage's input — the buffers are
+    // claimed BEFORE the lengths are exchanged, so that a rank without room says so in that exchange
     void* dst = d_out; size_t dcap = cap;
-    if (st + 1 < ns) {
-      const int slot = st & 1;
-      if (stagebuf[slot]) { (void)hipFree(stagebuf[slot]); stagebuf[slot] = nullptr; }
-      if (hipMalloc(&stagebuf[slot], ol + 256) != hipSuccess) return sErr(KX_E_HIP, "hipMalloc(stage buffer) failed");
-      dst = stagebuf[slot]; dcap = ol + 256;
-    } else {
-      res->out_len = ol; res->out_offset = off; res->total_out = total;
-      if (!d_out && cap == 0 && res_alloc) {   // (kx_run_fd_sharded: the library allocates the rank's output itself)
-        if (hipMalloc(&dst, ol + 256) != hipSuccess) return sErr(KX_E_HIP, "hipMalloc(output) failed");
-        *res_alloc = dst; dcap = ol + 256;
-      } else if (ol > cap || (ol && !d_out)) { res->boundary_ms = (float)boundary; return sErr(KX_E_CAPACITY, "output buffer too small"); }
+    if (!err) {
+      if (st + 1 < ns) {
+        const int slot = st & 1;
+        if (stagebuf[slot]) { (void)hipFree(stagebuf[slot]); stagebuf[slot] = nullptr; }
+        if (hipMalloc(&stagebuf[slot], ol + 256) != hipSuccess) local(sErr(KX_E_HIP, "hipMalloc(stage buffer) failed"));
+        dst = stagebuf[slot]; dcap = ol + 256;
+      } else if (!d_out && cap == 0 && res_alloc) {   // (kx_run_fd_sharded: the library allocates the rank's output itself)
+        if (hipMalloc(&dst, ol + 256) != hipSuccess) local(sErr(KX_E_HIP, "hipMalloc(output) failed"));
+        else { *res_alloc = dst; dcap = ol + 256; }
+      } else if (ol > cap || (ol && !d_out)) local(sErr(KX_E_CAPACITY, "output buffer too small"));
     }
+    {
+      LenMsg mine{ol, err ? 1u : 0u, 0u};
+      rc = gather(&mine, lens.data(), sizeof(LenMsg));
+      if (rc) return rc;
+      if ((rc = collective(lens))) return rc;
+    }
+    if (st + 1 == ns) {
+      uint64_t off = 0, total = 0;
+      for (int r = 0; r < world; ++r) { if (r < rank) off += lens[r].len; total += lens[r].len; }
+      res->out_len = ol; res->out_offset = off; res->total_out = total;
+    }
+    // (a failure of the emit itself is local again: it is reported by the next stage's first exchange, or — on the last
+    //  stage — by this rank's return code alone; no rank waits for another after this point)
     rc = kx_shard_emit(s, dst, dcap);
-    if (rc) return rc;
+    if (rc) { if (st + 1 == ns) { res->boundary_ms = (float)boundary; return rc; } local(rc); }
     cur = dst; curn = ol;
   }
   res->stats.in_bytes = n; res->stats.out_bytes = res->out_len;
@@ -324,9 +349,9 @@ int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, i
   std::vector<std::string> errs(ngpus);
   std::vector<kx_sharded_result> results(ngpus);
   std::mutex wm; std::condition_variable wcv; int next_writer = 0; bool abort_write = false;
+  int base_dev = 0; (void)hipGetDevice(&base_dev);   // the CALLER's current device (a fresh thread starts on device 0)
   auto body = [&](int r) {
     auto fail = [&](int code, const std::string& m) { rcs[r] = code; errs[r] = m; };
-    int base_dev = 0; (void)hipGetDevice(&base_dev);
     if (hipSetDevice(same ? base_dev : r) != hipSuccess) { fail(KX_E_HIP, "hipSetDevice failed"); }
     const uint64_t start = (uint64_t)r * L, len = r == ngpus - 1 ? n - start : L;
     kx_program* prog = nullptr; void *d_in = nullptr, *d_out = nullptr; std::vector<char> host;
@@ -383,8 +408,13 @@ int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, i
   kx_group_free(grp);
   int rc = 0;
   for (int r = 0; r < ngpus; ++r) if (rcs[r] && (!rc || rcs[r] == KX_MATCH_ERROR)) { rc = rcs[r]; if (rc != KX_MATCH_ERROR) kx_internal_set_error(errs[r].c_str()); }
-  if (stats) {
+  if (stats) {   // kernel times: the slowest rank's (the ranks run side by side); counts: summed
     *stats = results[0].stats;
+    for (int r = 1; r < ngpus; ++r) {
+      for (int i = 0; i < KX_NKERNELS; ++i) if (results[r].stats.kernel_ms[i] > stats->kernel_ms[i]) stats->kernel_ms[i] = results[r].stats.kernel_ms[i];
+      if (results[r].stats.total_ms > stats->total_ms) stats->total_ms = results[r].stats.total_ms;
+      stats->unsynced_segments += results[r].stats.unsynced_segments;
+    }
     stats->in_bytes = n; stats->out_bytes = results[0].total_out;
   }
   if (rc == 0 && out_seekable) {   // (pwrite does not move the descriptor's offset: leave it behind the output, as write would)

@@ -89,7 +89,8 @@ int main(int argc, char** argv) {
   int rc;
   if (gpus) {
     auto runs = (int (*)(const void*, size_t, int, int, int, kx_stats*))dlsym(h, "kx_run_fd_sharded");
-    if (!runs || phase) { fprintf(stderr, "%s: --gpus cannot be combined with --phase\n", argv[0]); return 1; }
+    if (phase) { fprintf(stderr, "%s: --gpus cannot be combined with --phase\n", argv[0]); return 1; }
+    if (!runs) { fprintf(stderr, "%s: this libkxhip.so has no kx_run_fd_sharded (--gpus needs the engine library of round 3 or later)\n", argv[0]); return 1; }
     rc = runs(blob.data(), blob.size(), (int)gpus, STDIN_FILENO, STDOUT_FILENO, &st);
   } else {
   kx_program* prog = nullptr;

@@ -151,9 +151,29 @@ FST oracleTransducer(const FST& f) {
     for (int i = w - 1; i >= 0; --i) { c[(size_t)i] = char(k & 0xFF); k >>= 8; }
     return c;
   };
+  // The engine's entries name at most KXP_ENGINE_TABLES tables beside each other (kxp_format.h).  A regex with more distinct
+  // multi-member predicates keeps table atoms for the LARGEST predicates (each of them would cost |p| byte classes written
+  // out) and writes the others out the way rounds 1-2 wrote all of them: |p| single-symbol edges, each followed by a lone
+  // ε-edge carrying that symbol's code — the same relation, symbol for symbol (`[a-c][d-f]…[v-x]` loads again).
+  auto tableOf = [](const ByteSet& p) { std::array<uint8_t, 256> t{}; int idx = 0; for (int x = 0; x < 256; ++x) if (p.has(x)) t[(size_t)x] = (uint8_t)idx++; return t; };
+  std::vector<std::pair<int, std::array<uint8_t, 256>>> cand;   // (−|p|, table), distinct
+  for (int q = 0; q < f.nstates; ++q)
+    for (const auto& e : f.sym[(size_t)q]) {
+      if (!e.copy || e.pred.size() <= 1) continue;
+      auto t = tableOf(e.pred);
+      bool seen = false;
+      for (auto& c : cand) seen = seen || c.second == t;
+      if (!seen) cand.push_back({-e.pred.size(), t});
+    }
+  size_t keep = KXP_ENGINE_TABLES;
+  if (const char* ev = getenv("KEXC_MAX_TABLE_ATOMS")) keep = (size_t)std::max(0, atoi(ev));
+  std::stable_sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+  if (cand.size() > keep) cand.resize(keep);
   FST o;
   o.nstates = f.nstates; o.init = f.init; o.is_final = f.is_final;
   o.eps.resize((size_t)f.nstates); o.sym.resize((size_t)f.nstates);
+  auto fresh = [&]() { o.eps.emplace_back(); o.sym.emplace_back(); o.is_final.push_back(0); return o.nstates++; };
+  for (auto& c : cand) o.tables.push_back(c.second);
   for (int q = 0; q < f.nstates; ++q) {
     const auto& es = f.eps[(size_t)q];
     for (size_t k = 0; k < es.size(); ++k)
@@ -161,13 +181,17 @@ FST oracleTransducer(const FST& f) {
     for (const auto& e : f.sym[(size_t)q]) {
       const int n = e.pred.size();
       if (!e.copy || n <= 1) { o.sym[(size_t)q].push_back({e.pred, false, e.to}); continue; }
-      std::array<uint8_t, 256> t{};
-      int idx = 0;
-      for (int x = 0; x < 256; ++x) if (e.pred.has(x)) t[(size_t)x] = (uint8_t)idx++;
+      const auto t = tableOf(e.pred);
       size_t k = 0;
       while (k < o.tables.size() && o.tables[k] != t) ++k;
-      if (k == o.tables.size()) o.tables.push_back(t);
-      o.sym[(size_t)q].push_back({e.pred, true, e.to, (int)k});
+      if (k < o.tables.size()) { o.sym[(size_t)q].push_back({e.pred, true, e.to, (int)k}); continue; }
+      int idx = 0;
+      for (int x = 0; x < 256; ++x) {
+        if (!e.pred.has(x)) continue;
+        const int s = fresh();
+        o.sym[(size_t)q].push_back({ByteSet::single(x), false, s});
+        o.eps[(size_t)s].push_back({code(n, idx++), e.to});
+      }
     }
   }
   return o;

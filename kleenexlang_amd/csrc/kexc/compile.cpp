@@ -309,6 +309,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
     for (uint32_t pi = 0; pi < pl->nprograms; ++pi) {
       const kexc_il_program& P = pl->programs[pi];
       auto bad = [&](const std::string& what) { throw CompileError("program " + std::to_string(pi) + ": " + what); };
+      if (P.ntests && P.ntables) bad("block form (ntests) with symbol tables: AppendTblI does not occur in a lookahead program (kexc_api.h)");
       if (P.ntests) {
         // block form (--la=true): tests are words of predicates.  The annotation alone defines the function: unroll it
         // over the leaves into single-symbol steps and build the tables from that (kexc.h: leafGraph); the blocks'
@@ -411,10 +412,12 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       for (uint32_t q = 0; q < P.nstates; ++q)
         if (t.final_act[q] != 0xFFFFFFFFu && t.final_act[q] < P.nactions)
           for (auto& m : t.actions[t.final_act[q]]) if (m.op == 4) bad("AppendTblI in a final action (no symbol to index with)");
-      bool native_tables = uses_tables && !getenv("KEXC_LOWER_TABLES");
+      // (a stage with register actions takes no table atoms — the engine's parseStage refuses the pair — and the engine's entries
+      //  name at most KXP_ENGINE_TABLES tables: both go the written-out way)
+      bool native_tables = uses_tables && !getenv("KEXC_LOWER_TABLES") && !P.has_actions && P.ntables <= KXP_ENGINE_TABLES;
       for (uint32_t k = 0; k < P.ntables; ++k) native_tables = native_tables && P.tbl_width[k] == 1;
       for (uint32_t e : t.back) native_tables = native_tables && (e == 0xFFFFFFFFu || (e >> 9) < (1u << 15));
-      if (native_tables && P.ntables <= KXP_MAX_TABLES) {
+      if (native_tables) {
         // one-byte tables stay TABLE ATOMS (round 3): micro-op 4 as it is, the path entry copies through its table
         for (uint32_t k = 0; k < P.ntables; ++k) { std::array<uint8_t, 256> tb; memcpy(tb.data(), P.tbl_data + tbl_at[k], 256); t.tables.push_back(tb); }
         for (size_t i = 0; i < btab.size(); ++i) if (btab[i] != 0xFFFFFFFFu) t.back[i] |= 0x100u | ((btab[i] + 1) << 24);

@@ -339,8 +339,20 @@ void shapeKey(const Tree& t, std::string& k) {
 
 }  // namespace
 
-SST determinize(const FST& f) {
+SST determinize(const FST& f, size_t table_word_cap) {
   Determinizer D(f);
+  // Fail fast for a back end with a table limit (the engine: (states + 1) x classes <= 65535 words even in its BIG form).  The
+  // byte classes are the coarsest partition refining every edge predicate, so the partition of the predicates SEEN SO FAR
+  // only gets finer and the states only get more: once (states so far) x (classes so far) is over the limit the finished
+  // machine is too (bench/kleenex/src/syntax.kex ran for 40 minutes before saying so).
+  uint8_t cls_of[256] = {0}; int ncls_lb = 1;
+  auto refine = [&](const ByteSet& p) {
+    int split[256]; for (int c = 0; c < ncls_lb; ++c) split[c] = -2;   // -2 unseen, -1 seen outside p only / inside p only, >= 0 new class for members
+    bool in0[256] = {false}, out0[256] = {false};
+    for (int b = 0; b < 256; ++b) (p.has(b) ? in0 : out0)[cls_of[b]] = true;
+    for (int c = 0, n = ncls_lb; c < n; ++c) if (in0[c] && out0[c]) split[c] = ncls_lb++;
+    for (int b = 0; b < 256; ++b) if (p.has(b) && split[cls_of[b]] >= 0) cls_of[b] = (uint8_t)split[cls_of[b]];
+  };
   std::map<std::vector<int>, int> varIds;          // Var [Int] (reversed path) → register id
   auto varOf = [&](const std::vector<int>& path) {
     auto it = varIds.find(path);
@@ -416,6 +428,12 @@ SST determinize(const FST& f) {
       MTree b = D.consumeTree(*a, p); if (!b) continue;
       MTree c = D.closeTree(*b); if (!c) continue;
       SSTEdge edge; edge.pred = p;
+      if (table_word_cap) {
+        if (ncls_lb < 256) refine(p);
+        if ((skels.size() + 1) * (size_t)ncls_lb > table_word_cap)
+          throw CompileError("program outside engine limits: more than " + std::to_string(skels.size()) + " SST states x " + std::to_string(ncls_lb) +
+                             " byte classes (the engine's state table holds " + std::to_string(table_word_cap) + " transition words); --backend=c compiles it for the CPU");
+      }
       // path form: per leaf of the new tree, origin leaf + the atoms after the VAR prefix
       std::function<void(const Tree&, UpdateString)> walk = [&](const Tree& t, UpdateString acc) {
         acc.insert(acc.end(), t.out.begin(), t.out.end());

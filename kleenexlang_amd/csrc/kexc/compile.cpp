@@ -40,7 +40,7 @@ Compiled compileSource(const std::string& src, const std::string& srcname, const
     // --la=true: the lookahead machine (word tests) is built as the reference builds it, then unrolled over its leaves
     // into single-symbol steps — the tables stay (state, class) tables and write what the lookahead machine writes
     if (o.la) f = leafGraph(determinizeWords(f));
-    SST sst = determinize(f);                 // singletonMode
+    SST sst = determinize(f, o.backend == "hip" && !getenv("KEXC_NO_TABLE_CAP") ? 65535 : 0);   // singletonMode
     optimizeSST(sst, o.opt);
     out.sst_states.push_back((int)sst.states.size());
     out.stages.push_back(lower(sst, sst));

@@ -152,7 +152,7 @@ struct SST {
   std::vector<std::string> init_path;  // output accumulated on each leaf of the initial closure
   std::vector<std::array<uint8_t, 256>> tables;   // the transducer's symbol tables (FST::tables)
 };
-SST determinize(const FST& f);             // sstFromFST … singletonMode=True  (--la=false)
+SST determinize(const FST& f, size_t table_word_cap = 0);   // table_word_cap != 0: give up as soon as (states + 1) x classes must exceed it             // sstFromFST … singletonMode=True  (--la=false)
 
 // The path form of the lookahead machine (sstFromFST … singletonMode=False, `--la=true`, the reference's default): a
 // block tests WORDS of predicates — the single symbols of the coarsest partition plus the longest deterministic prefix

@@ -218,3 +218,64 @@ def test_table_atoms_on_the_engine(tmp_path, monkeypatch):
                     p.close()
         for k in env:
             monkeypatch.delenv(k)
+
+
+# ------------------------------------------------------------------ register actions at the seam
+def _action_vectors():
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "action_vectors.json"), encoding="utf-8") as f:
+        return json.load(f)["line_tests"]
+
+
+def _marshal_with_actions(stage):
+    """A stage whose output is a token stream (kxp_format.h: FF 00 Push, FF 01 r Pop r, FF 02 r Write r, FF FF = byte FF) the way a
+    front end hands it over: the ordinary tables + has_actions / action_regs (include/kexc_api.h)."""
+    d = marshal(stage)
+    d["has_actions"], d["action_regs"] = int(stage.actions & 1), int(stage.actions >> 8)
+    return d
+
+
+def test_action_program_marshalled_through_the_seam(tmp_path):
+    """What a front end compiling with the reference's default flags (`--act=true`) must do for a program with register actions
+    (`constructTransducerInBand`): hand over ONE transducer per stage whose output carries Push / Pop r /
+    Write r in band, with has_actions / action_regs set.  Here the reference's two action vectors (actionbug, makeDanish) go that
+    way — tables taken apart, marshalled by hand through ctypes, put together again by kexc_emit_pipeline — and give the
+    reference's `// OUT:` lines (tests/golden/action_vectors.json), in the register form and in the path form."""
+    from conftest import line_expected, line_input, same_modulo_trailing_newlines
+    for t in _action_vectors():
+        stages = kxp.parse(blob_of(t["program"], 0))
+        assert any(s.actions & 1 for s in stages), t["name"]
+        out = tmp_path / (t["name"] + ".kxp")
+        assert emit_pipeline([_marshal_with_actions(s) for s in stages], srcout=out) == 0
+        again = out.read_bytes()
+        assert [s.actions for s in kxp.parse(again)] == [s.actions for s in stages]
+        for pf in (False, True):
+            got = oracle.run(again, line_input(t["in"]), path_form=pf)
+            assert same_modulo_trailing_newlines(got, line_expected(t["out"])), (t["name"], pf, got)
+    # without the flag the same tables are an ordinary rewriter: the tokens come out as bytes
+    s0 = kxp.parse(blob_of(_action_vectors()[0]["program"], 0))
+    plain = marshal(s0[0])
+    assert emit_pipeline([plain], srcout=tmp_path / "plain.kxp") == 0
+    assert b"\xff" in oracle.run((tmp_path / "plain.kxp").read_bytes(), b"c\n")
+
+
+@pytest.mark.gpu
+def test_action_program_from_the_seam_runs_on_the_engine(tmp_path):
+    """…and the blob that kexc_emit_pipeline builds from the marshalled action program runs on the GPU (transducer kernels + the
+    action post-pass) and writes the reference's expected lines; a long input of the same shape against the oracle."""
+    from conftest import line_expected, line_input, same_modulo_trailing_newlines
+    from kleenexlang_amd import host
+    for t in _action_vectors():
+        stages = kxp.parse(blob_of(t["program"], 0))
+        out = tmp_path / (t["name"] + ".kxp")
+        assert emit_pipeline([_marshal_with_actions(s) for s in stages], srcout=out) == 0
+        blob = out.read_bytes()
+        p = host.Program(blob)
+        try:
+            got = p.run_host(line_input(t["in"]))
+            assert same_modulo_trailing_newlines(got, line_expected(t["out"])), (t["name"], got)
+            big = line_input(t["in"]) * 3000
+            assert p.run_host(big) == oracle.run(blob, big), t["name"]
+        finally:
+            p.close()

@@ -361,3 +361,53 @@ def test_random_regex_coders_on_the_engine():
             runs += 1
         prog.close()
     assert runs >= 100
+
+
+# ------------------------------------------------------------------ the reference's own regex sources, pinned by hand
+def _coder_vectors():
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "coder_vectors.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_reference_regex_sources_against_hand_derived_codes():
+    """the codes of bench/regex_src/as.rx and csv_project3.rx on small inputs, derived by hand from
+    OracleMachine.hs:47-61 + Util/Coding.hs:13-19 + Desugaring.hs:70-118 (tests/golden/coder_derivation.md — a worked derivation,
+    not a second program) — against the compiler (`--opt 0/3`, `--la` off/on), in the register form and in the path form.  This
+    pins the coder on what the reference's two sources use: star, negated class, singleton reads, groups, concatenation."""
+    v = _coder_vectors()
+    ref_src = "/root/reference/bench/regex_src"
+    if os.path.isdir(ref_src):   # the committed regex text is the reference's file, byte for byte
+        for name, rx in v["sources"].items():
+            assert open(os.path.join(ref_src, name + ".rx"), "rb").read().rstrip(b"\n") == rx.encode(), name
+    for opt in (0, 3):
+        blobs = {name: host.compile_regex(rx, opt=opt) for name, rx in v["sources"].items()}
+        for t in v["vectors"]:
+            data = bytes.fromhex(t["in_hex"])
+            for pf in (False, True):
+                if t["code_hex"] is None:
+                    with pytest.raises(oracle.OracleMatchError):
+                        oracle.run(blobs[t["source"]], data, path_form=pf)
+                else:
+                    assert oracle.run(blobs[t["source"]], data, path_form=pf) == bytes.fromhex(t["code_hex"]), (t, opt, pf)
+
+
+@pytest.mark.gpu
+def test_reference_regex_sources_on_the_engine():
+    """…and the engine writes the hand-derived codes (tests/golden/coder_vectors.json)."""
+    v = _coder_vectors()
+    for name, rx in v["sources"].items():
+        p = host.Program(host.compile_regex(rx))
+        try:
+            for t in v["vectors"]:
+                if t["source"] != name:
+                    continue
+                data = bytes.fromhex(t["in_hex"])
+                if t["code_hex"] is None:
+                    with pytest.raises(host.MatchError):
+                        p.run_host(data)
+                else:
+                    assert p.run_host(data) == bytes.fromhex(t["code_hex"]), t
+        finally:
+            p.close()

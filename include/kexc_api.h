@@ -99,7 +99,10 @@ typedef struct kexc_il_program {
  * contents of `r@t`), not the pending output of undecided paths, so it has no path form.  Register actions reach the
  * engine the other way: ONE program per stage whose output carries the actions in band (has_actions below) and the
  * action post-pass on the device (`kexc_compile` does this for Kleenex source). */
-typedef struct kexc_pipeline { int is_oracle_action; uint32_t nprograms; const kexc_il_program* programs; } kexc_pipeline;
+/* program_size = sizeof(kexc_il_program) as the CALLER was compiled: programs[] is an array of records of that size, and the record
+ * has grown from round to round (symbol tables, the block form) — a caller built against an older header is refused with a
+ * message instead of being read with the wrong stride. */
+typedef struct kexc_pipeline { int is_oracle_action; uint32_t nprograms; const kexc_il_program* programs; uint32_t program_size; } kexc_pipeline;
 
 /* compileProgram (src/KMC/Program/Backends/C.hs:529-540), argument for argument:
  *   CType buffer unit        -> buffer_unit_bits (8; 16/32/64 are refused: `--wordsize` other than 8 is not built)

@@ -155,6 +155,59 @@ def sweep2(inl=False):
     return L
 
 
+def sweep2b():
+    """piece_sweep2 with BRANCH-FREE job noting (round 4).  The vote-and-rank form of sweep2 handles the jobs of a step pair under
+    `s_and_saveexec … s_cbranch_execz`, with a second branch for lanes that have a constant on both chains: two branches and a
+    dozen dependent scalar operations per step pair, 265 cycles per step pair on the wave's clock (KX_DEBUG_FLAGS=64 timeline)
+    against the ~120 of the dependent LDS read the sweep is built around.  Here every step of each chain runs the same straight
+    code: rank among the lanes with a constant (v_mbcnt over the compare's mask), slot address, -1 (out of range: the hardware
+    drops the store) for lanes without one, one store; two scalar ops advance the wave's slot counter."""
+    L = []
+    ap = L.append
+    row = lambda t: "%%[bo%d]" % (t >> 1)
+    wsel = lambda t: "WORD_%d" % (t & 1)
+    base = {"A": 32, "B": 0}
+    ap("s_setprio 3")
+    for ch in "AB":
+        t = base[ch] + 31
+        ap("v_add_u32_sdwa %%[a%s0], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, row(t), ch, SD, wsel(t)))
+        ap("ds_read_b32 %%[e%s0], %%[a%s0]" % (ch, ch))
+    for j in range(31, -1, -1):
+        cur, nxt = (31 - j) & 1, (32 - j) & 1
+        # in flight, oldest first: the two entry reads, then the previous step's two byte stores and two job stores
+        ap("s_waitcnt lgkmcnt(%d)" % (0 if j == 31 else 4))
+        for ch in "AB":
+            ap("v_and_b32 %%[leaf%s], 0x3fc, %%[e%s%d]" % (ch, ch, cur))
+            if j > 0:
+                t = base[ch] + j - 1
+                ap("v_add_u32_sdwa %%[a%s%d], %s, %%[leaf%s] %s src0_sel:%s src1_sel:DWORD" % (ch, nxt, row(t), ch, SD, wsel(t)))
+                ap("ds_read_b32 %%[e%s%d], %%[a%s%d]" % (ch, nxt, ch, nxt))
+        for ch in "AB":
+            t = base[ch] + j
+            e, o, a = "%%[e%s%d]" % (ch, cur), "%%[o%s]" % ch, "%%[a%s%d]" % (ch, cur)
+            by = t & 3
+            if by == 3:
+                ap("v_lshrrev_b32 %%[tw%s], 8, %%[w%d]" % (ch, t >> 2))
+            src = "%%[tw%s]" % ch if by in (1, 3) else "%%[w%d]" % (t >> 2)
+            wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            ap("v_sub_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, e, SD))
+            ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % e)
+            ap("v_lshl_or_b32 %s, %s, 31, %s" % (e, e, o))
+            ap("%s %s, %s" % (wr, e, src))
+            # the job (e is free now: it becomes the slot address)
+            ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % e)
+            ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (e, e))
+            ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (e, e))
+            ap("v_min_u32 %s, %%[jlim], %s" % (e, e))
+            ap("v_cndmask_b32_e32 %s, -1, %s, vcc" % (e, e))
+            ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
+            ap("ds_write_b32 %s, %s" % (e, a))
+            ap("s_bcnt1_i32_b64 %[st], vcc")
+            ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
+    ap("s_setprio 0")
+    return L
+
+
 def sweep2j():
     """job-stride layout: lane-private job lists, unconditional job stores (see the module docstring)"""
     L = []
@@ -330,6 +383,17 @@ def main():
             sweep2(),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[mA] "=&s"(mA)', '[mU] "=&s"(mU)', '[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
                                                        '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
+            ['[jlim] "s"(jlim)'],
+            '"vcc", "scc", "memory"')
+    tmpb = ["eA0", "eA1", "eB0", "eB1", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
+    emit_fn(out, "piece_sweep2b",
+            "const uint32_t (&bo)[32], const uint32_t (&w)[16], uint32_t leafA, uint32_t oA, uint32_t leafB, uint32_t oB, "
+            "uint32_t& jb, uint32_t jlim",
+            "uint32_t " + ", ".join(tmpb) + ", st;",
+            sweep2b(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmpb] + ['[st] "=&s"(st)', '[leafA] "+v"(leafA)', '[oA] "+v"(oA)',
+                                                        '[leafB] "+v"(leafB)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
             ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)] + ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] +
             ['[jlim] "s"(jlim)'],
             '"vcc", "scc", "memory"')

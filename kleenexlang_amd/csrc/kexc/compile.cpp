@@ -301,6 +301,9 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
   try {
     using namespace kexc;
     if (!pl || !pl->programs || pl->nprograms == 0) throw CompileError("empty pipeline");
+    if (pl->program_size != sizeof(kexc_il_program))
+      throw CompileError("kexc_pipeline.program_size is " + std::to_string(pl->program_size) + ", this library's kexc_il_program has " +
+                         std::to_string(sizeof(kexc_il_program)) + " bytes: the caller was built against another version of include/kexc_api.h");
     if (buffer_unit_bits != 8) throw CompileError("buffer unit must be 8 bits (UInt8T): the engine's output is a byte stream (--wordsize 8)");
     if (pl->is_oracle_action) throw CompileError("oracle/action pipelines (Right [(Program, Program)]) are not taken: the action program's registers hold data (ActionSST.hs:47-104), "
                                                     "not path choices, so it has no path form; hand over the transducer with its actions in band instead (has_actions, kxp_format.h) "

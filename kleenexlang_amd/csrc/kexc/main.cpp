@@ -47,6 +47,8 @@ static int usage() {
                "       kexc simulate|interpret [--sim lockstep|backtrack|sst] [--quiet] [--opt N] [--act[=BOOL]] FILE.kex  < in > out\n"
                "                    (sst: the compiled program on the HIP engine; lockstep (default), backtrack: the FST simulators,\n"
                "                     on the CPU; `interpret` = `simulate --quiet`)\n"
+               "--la defaults to false here (the reference: true, Options.hs:153): both machines write the same bytes\n"
+               "(Tests/Regression.hs:45-53); the direct tables have fewer states, and the path form has no registers for lookahead to save.\n"
                "The reference's `visualize` subcommand is not part of this build.\n";
   return 1;
 }

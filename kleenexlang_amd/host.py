@@ -304,11 +304,12 @@ class KexcIlProgram(ctypes.Structure):
 
 
 class KexcPipeline(ctypes.Structure):
-    _fields_ = [("is_oracle_action", ctypes.c_int), ("nprograms", ctypes.c_uint32), ("programs", ctypes.POINTER(KexcIlProgram))]
+    _fields_ = [("is_oracle_action", ctypes.c_int), ("nprograms", ctypes.c_uint32), ("programs", ctypes.POINTER(KexcIlProgram)),
+                ("program_size", ctypes.c_uint32)]
 
 
 def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bits=8, copt=3, cc="cc", word_alignment=True,
-                  oracle_action=False, info=None):
+                  oracle_action=False, info=None, program_size=None):
     """compileProgram's seam (include/kexc_api.h::kexc_emit_pipeline): `programs` is a list of dicts of numpy arrays
     (keys = the fields of kexc_il_program).  Returns the exit code; raises CompileError with the message on failure."""
     import numpy as np
@@ -347,7 +348,7 @@ def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bi
                 a = np.zeros(1, dtype=dt)
             keep.append(a)
             setattr(st, k, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8 if dt == np.uint8 else ctypes.c_uint16 if dt == np.uint16 else ctypes.c_uint32)))
-    pl = KexcPipeline(1 if oracle_action else 0, len(programs), structs)
+    pl = KexcPipeline(1 if oracle_action else 0, len(programs), structs, ctypes.sizeof(KexcIlProgram) if program_size is None else program_size)
     CB = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_void_p)
     cb = CB((lambda line, ctx: info(line.decode())) if info else (lambda line, ctx: None))
     lib.kexc_emit_pipeline.argtypes = [ctypes.c_int, ctypes.c_int, CB, ctypes.c_void_p, ctypes.POINTER(KexcPipeline), ctypes.c_char_p,

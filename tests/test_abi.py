@@ -144,7 +144,15 @@ def test_big_table_programs_pass_validation():
     assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 100 * 1024
     host.validate_blob(blob)
     src, _ = dictionary_program(nwords=100, lo=25, hi=32)
-    blob = blob_of(src, opt=0)
+    # round 4: the compiler itself gives up as soon as the states and classes found so far prove the table too large …
+    with pytest.raises(host.CompileError, match="outside engine limits: more than [0-9]+ SST states x [0-9]+ byte classes"):
+        host.compile_source(src, opt=0)
+    # … and a blob that reaches the engine anyway (a front end without that check) is refused at load
+    os.environ["KEXC_NO_TABLE_CAP"] = "1"
+    try:
+        blob = host.compile_source(src, opt=0)
+    finally:
+        del os.environ["KEXC_NO_TABLE_CAP"]
     info = oracle.info(blob)
     assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 256 * 1024
     with pytest.raises(host.EngineError, match="outside engine limits"):

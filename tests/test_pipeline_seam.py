@@ -90,6 +90,8 @@ def test_multi_stage_and_argument_errors(tmp_path):
         emit_pipeline([flip_ab_program()], srcout=out, buffer_unit_bits=16)     # --wordsize 16 is not built
     with pytest.raises(CompileError, match="oracle/action"):
         emit_pipeline([flip_ab_program(), flip_ab_program()], srcout=out, oracle_action=True)
+    with pytest.raises(CompileError, match="another version of include/kexc_api.h"):
+        emit_pipeline([flip_ab_program()], srcout=out, program_size=200)          # a caller built against an older record
     bad = flip_ab_program(); bad["delta"] = [0, 7, 0, 0xFFFF]
     with pytest.raises(CompileError, match="out of range"):
         emit_pipeline([bad], srcout=out)

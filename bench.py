@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ≈6.3 TB/s achievable)
+# with today's instruction counts per 4 KiB (k_forward + k_backlen + k_emit, SQ counters of profiles/r04z_*) and the
+# measured ≈ 3.7 SIMD-cycles per wave-instruction the three kernels cannot run faster than this fraction of 8 TB/s.
+ISSUE_BOUND_FRAC = {"apache_log": 0.101}
 
 
 def cpu_baseline(program, base, sample_bytes):
@@ -261,6 +264,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_input_byte": 1.0},
+            # How far `frac` is from what is possible: a perfect single-pass engine moves 1 B in + r B out per input
+            # byte over a bus that sustains ≈ 6.3 TB/s in mixed traffic; this three-pass design moves 3 + r + 3/16 B.  Both are
+            # bounds of the WHOLE PATH (compare `whole_path.frac_of_hbm_peak`), stated as fractions of the 8 TB/s read roofline.
+            "ceilings": {"out_over_in": round(ratio, 4),
+                         "single_pass_hbm_bound_frac": round(6300.0 / (1.0 + ratio) / HBM_PEAK_GBPS, 4),
+                         "this_design_hbm_bound_frac": round(6300.0 / (3.0 + ratio + 3.0 / 16.0) / HBM_PEAK_GBPS, 4),
+                         "this_design_issue_bound_frac": ISSUE_BOUND_FRAC.get(a.program),
+                         "note": "fractions of 8 TB/s; north_star's 40 % is above the single-pass HBM bound for this output ratio; the issue bound is "
+                                 "instructions per 4 KiB x ~3.7 SIMD-cycles each (measured, DESIGN.md §4), the limit this engine actually runs into"},
             "whole_path": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,
                            "frac_of_hbm_peak": round(n_local / (ksum / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if ksum else None},
             "dominant_kernel_own_traffic": {"bytes_per_input_byte": round(alg[dom], 4),

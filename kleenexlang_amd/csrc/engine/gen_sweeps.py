@@ -281,8 +281,11 @@ def fwd1(pack):
     return L
 
 
-def walk1():
-    """backward walk that only measures: leaf chain + appended-byte sum, with the state in the middle of the piece"""
+def walk1(count=False):
+    """backward walk that only measures: leaf chain + appended-byte sum, with the state in the middle of the piece.
+    count (job-stride layout, byte 2 of an entry = 4 where a constant follows): the SAME add takes the entry's upper half-word,
+    so the sum's low byte counts the constants (x 4) while bits 8.. add up the appended bytes — the count costs no instruction.
+    The low byte is cleared in the middle (32 steps x 4 fit a byte, 64 would not)."""
     L = []
     ap = L.append
     ap("s_setprio 2")
@@ -291,10 +294,12 @@ def walk1():
         ap("ds_read_b32 %[e], %[a]")
         ap("s_waitcnt lgkmcnt(0)")
         ap("v_and_b32 %[leaf], 0x3fc, %[e]")
-        ap("v_add_u32_sdwa %%[sum], %%[sum], %%[e] %s src0_sel:DWORD src1_sel:BYTE_3" % SD)
+        ap("v_add_u32_sdwa %%[sum], %%[sum], %%[e] %s src0_sel:DWORD src1_sel:%s" % (SD, "WORD_1" if count else "BYTE_3"))
         if t == 32:
             ap("v_mov_b32 %[lmid], %[leaf]")
             ap("v_mov_b32 %[shi], %[sum]")
+            if count:
+                ap("v_and_b32 %[sum], 0xffffff00, %[sum]")
     ap("s_setprio 0")
     return L
 
@@ -435,6 +440,13 @@ def main2(out):
             fwd1(False),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[h] "+v"(h)'],
             ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
+            '"memory"')
+    emit_fn(out, "piece_walk1j",
+            "const uint32_t (&bo)[32], uint32_t& leaf, uint32_t& sum, uint32_t& lmid, uint32_t& shi",
+            "uint32_t a, e;",
+            walk1(True),
+            ['[a] "=&v"(a)', '[e] "=&v"(e)', '[lmid] "=&v"(lmid)', '[shi] "=&v"(shi)', '[leaf] "+v"(leaf)', '[sum] "+v"(sum)'],
+            ['[bo%d] "v"(bo[%d])' % (i, i) for i in range(32)],
             '"memory"')
     emit_fn(out, "piece_walk1",
             "const uint32_t (&bo)[32], uint32_t& leaf, uint32_t& sum, uint32_t& lmid, uint32_t& shi",

@@ -1,0 +1,17 @@
+#!/bin/bash
+ulimit -c 0; export HSA_COREDUMP_PATTERN=/dev/null
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r04h}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+timeout 1500 python -m pytest tests/test_engine_gpu.py -m gpu -x -q -k "not 10gib and not rccl" > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt; tail -3 $O/pytest.txt
+run() { # name env...
+  local name=$1; shift
+  env "$@" KX_DEBUG=1 timeout 600 python bench.py --program $P --steps 5 --warmup 1 --no-cpu > $O/bench_${P}_$name.json 2> $O/bench_${P}_$name.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/bench_${P}_$name.json").read()); print("$P $name", d["value"], d["ms_per_step"], d["kernels_ms"], d["output_checked_bit_exact"])
+except Exception as e: print("$P $name", "FAILED", e); print(open("$O/bench_${P}_$name.err").read()[-800:])
+PY
+}
+for P in apache_log csv2json iso_datetime_to_json thousand_sep; do
+  run two X=1; run one KX_DEBUG_FLAGS=512; run two2 X=1; run one2 KX_DEBUG_FLAGS=512
+done

@@ -457,12 +457,15 @@ struct Desugarer {
         std::vector<int> ids(e->lo, ie);
         if (!e->has_hi) { ids.push_back(star(re(out, e->a), false)); return decl(seqT(ids)); }
         if (e->hi == e->lo) return decl(seqT(ids));
-        // Standard meaning e{n,m} = eⁿ (e?)^(m-n); see DESIGN.md "parity unpinned" for the
-        // reference's `replicate m'` (Desugaring.hs:106-115), which coincides on all
-        // reference vectors (n == 0 or n == m).
+        // The reference's regex desugaring appends m OPTIONAL copies behind the n mandatory ones — `replicate n ie ++ replicate m'
+        // iquest`, Desugaring.hs:106-115 — not m - n as its Kleenex-term desugaring does (:150-160): /x{1,3}/ accepts one to FOUR x.
+        // Followed to the letter since round 4 (rounds 1-3 used m - n: same output on every accepted input of the standard meaning,
+        // but e.g. csv2json's /[0-9]{1,3}/ octets then rejected a four-digit octet that the reference's binary accepts).
+        // KEXC_STANDARD_RANGES=1 restores m - n (SURVEY App. E's state counts were made with it).
+        const int nopt = getenv("KEXC_STANDARD_RANGES") ? e->hi - e->lo : e->hi;
         int ieps = decl(seqT({}));
         int iq = decl(sumT({ie, ieps}));
-        for (int k = 0; k < e->hi - e->lo; ++k) ids.push_back(iq);
+        for (int k = 0; k < nopt; ++k) ids.push_back(iq);
         return decl(seqT(ids));
       }
       case Regex::Suppress: return re(false, e->a);

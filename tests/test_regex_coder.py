@@ -149,7 +149,8 @@ def greedy_code(regex, data):
             return m(node[1], i, code, lambda j, c: m(("star", node[1], node[2]), j, c, k))
         if kind == "rep":
             _, e, lo, hi = node
-            seq = [e] * lo + ([("star", e, False)] if hi is None else [("opt", e, False)] * (hi - lo))
+            # Desugaring.hs:106-115: n mandatory copies, then — when n != m — m OPTIONAL ones (`replicate m' iquest`, not m - n)
+            seq = [e] * lo + ([("star", e, False)] if hi is None else [] if hi == lo else [("opt", e, False)] * hi)
             if not seq:
                 return k(i, code)
             tree = seq[0]

@@ -147,12 +147,18 @@ typedef struct kx_sharded_result {
   float boundary_ms;   /* wall time this rank spent inside the all-gathers (waiting for the slowest rank included) */
   kx_stats stats;      /* kernel times summed over the stages; fail_pos / fail_stage on a match error */
 } kx_sharded_result;
+/* (collective return code: every record of the three exchanges carries the sender's status, so a local failure — out of memory,
+ *  a HIP error — ends the call on EVERY rank instead of leaving the others inside an all-gather) */
 int kx_run_sharded(kx_program* prog, int rank, int world, kx_allgather_fn ag, void* ag_ctx, const void* d_in, size_t n,
                    void* d_out, size_t cap, kx_sharded_result* res, void* stream);
 
 /* The produced binary's `--gpus N`: stdin must be a regular file; it is cut into N contiguous shards (4 KiB multiples), one
  * thread and one program instance per GPU, hand-off through host memory (kx_group_*); the output is written at each rank's
- * offset (regular file) or in rank order (pipe).  Same return codes and match-error position as kx_run_fd. */
+ * offset (regular file) or in rank order (pipe).  Same return codes and match-error position as kx_run_fd.
+ * Limits: every rank holds its WHOLE shard and its output in device memory (no windows, unlike kx_run_fd): an input beyond
+ * about N x 100 GB fails with "cannot place the shard on the device".  stats: kernel times of the slowest rank, counts summed.
+ * The return code is collective (kx_run_sharded): a rank that fails locally says so in the next exchange and every rank
+ * returns — its own code and message, or KX_E_IO naming the failing rank. */
 int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, int out_fd, kx_stats* stats);
 
 typedef struct kx_comm kx_comm;

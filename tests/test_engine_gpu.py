@@ -377,6 +377,42 @@ def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
         assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]
 
 
+def test_sharded_run_reports_a_local_failure_on_every_rank():
+    """kx_run_sharded's return code is collective.  One of three ranks has no room for its output (a local failure
+    between two exchanges); every rank must come back with an error — the failing one with its own message, the others naming
+    it — instead of waiting in the next all-gather for a peer that has already returned."""
+    import threading
+    import torch
+    from kleenexlang_amd.host import EngineError, Group
+    blob = blob_of("apache_log")
+    data = workloads.generate("apache_log", 2 << 20, 12)
+    world = 3
+    grp = Group(world)
+    L = (len(data) // world) // 4096 * 4096
+    errs, done = [None] * world, [False] * world
+
+    def body(r):
+        lo, hi = r * L, (len(data) if r == world - 1 else (r + 1) * L)
+        p = Program(blob)
+        t = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8).to("cuda:0")
+        out = torch.empty(4 * (hi - lo) + 65536, dtype=torch.uint8, device="cuda:0")
+        mb = grp.member(r)
+        try:
+            p.run_sharded(r, world, mb, t.data_ptr(), hi - lo, out.data_ptr(), 4096 if r == 1 else out.numel())   # rank 1: 4 KiB of room
+        except Exception as e:   # noqa: BLE001
+            errs[r] = e
+        finally:
+            done[r] = True
+            mb.close(); p.close()
+    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    grp.close()
+    assert all(done), "a rank is still waiting for its peers"
+    assert all(isinstance(e, EngineError) for e in errs), errs
+    assert "too small" in str(errs[1]) and all("rank 1" in str(errs[r]) for r in (0, 2)), errs
+
+
 def test_c_driver_shards_inside_one_process_and_in_the_binary(tmp_path):
     """kx_run_sharded (include/kxhip.h): the boundary hand-off is run by the library itself.  (1) Three and five ranks as
     threads of this process, exchange through kx_group_*: shards cut mid-line, a two-stage pipeline, a rejected input

@@ -377,6 +377,34 @@ def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
         assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]
 
 
+def test_layout_follows_the_constants_per_piece_of_earlier_shards(tmp_path):
+    """Round 4: a stage that qualifies keeps two table images — vote-and-rank job noting and the job-stride layout with counted job
+    slots — and every shard (a run of the program object, a window of a streamed input) picks the one that suits the constants per
+    piece the shards before it held: iso_datetime_to_json (21 per piece) moves to the job-stride layout after its first shard,
+    apache_log (4) stays.  Same bytes either way: consecutive runs on one Program, and a produced binary streaming its input in
+    small windows (the switch happens in mid-stream)."""
+    import subprocess
+    from kleenexlang_amd import build, program_path
+    for prog, shape in (("iso_datetime_to_json", "datetime"), ("apache_log", "apache_log"), ("csv2json", "csv")):
+        blob = blob_of(prog)
+        data = workloads.generate(shape, 3 << 20, 21)
+        want = oracle.run(blob, data)
+        p = Program(blob)
+        try:
+            for i in range(4):
+                assert p.run_host(data) == want, (prog, i)
+            assert p.run_host(data[:70000].rsplit(b"\n", 1)[0] + b"\n") == oracle.run(blob, data[:70000].rsplit(b"\n", 1)[0] + b"\n")
+        finally:
+            p.close()
+    exe = tmp_path / "iso"
+    assert subprocess.run([os.path.join(build.OUT, "kexc"), "compile", "--quiet", program_path("iso_datetime_to_json"), "--out", str(exe)]).returncode == 0
+    data = workloads.generate("datetime", 2 << 20, 22)
+    want = oracle.run(blob_of("iso_datetime_to_json"), data)
+    r = subprocess.run([str(exe)], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, KX_WINDOW_BYTES="262144", KX_DEBUG="1"))
+    assert r.returncode == 0 and r.stdout == want
+    assert b"layout=vote-and-rank" in r.stderr and b"layout=job-stride" in r.stderr    # both layouts ran inside this one stream
+
+
 def test_sharded_run_reports_a_local_failure_on_every_rank():
     """kx_run_sharded's return code is collective.  One of three ranks has no room for its output (a local failure
     between two exchanges); every rank must come back with an error — the failing one with its own message, the others naming

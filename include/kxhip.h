@@ -85,6 +85,34 @@ uint32_t kx_num_stages(const kx_program* prog);
  * across GPUs (SURVEY §8e "pathological case": the boundary tuple would be O(N)). */
 int kx_stage_has_actions(const kx_program* prog, uint32_t stage);
 
+/* ---- the delayed form of a stage (round 5; kleenexlang_amd/csrc/engine/kx_delayed.h) -----------------------------------
+ * Where every step's output is decided by at most K further input symbols the engine runs the stage as a forward transducer
+ * with fixed delay K — a forward pass for the lengths and one fused walk that places the bytes; no backward pass.  A context
+ * that K symbols do not decide is noticed at run time and the shard is redone by the general engine (and the stage's later
+ * shards go there directly): results never depend on which engine ran.  Environment: KX_DF=0 switches the delayed form off,
+ * KX_DF=2 takes it whatever the share of undecided contexts, KX_DF_K=1|2 sets the delay (default 2).
+ * kx_df_describe needs no device: it builds the form from the blob (as kx_load does) and reports it; `image`, if not NULL,
+ * receives up to image_cap bytes of the table image (class*8 u8[256] | rows of C x {lo = handle of the next state's row,
+ * hi = what the step writes: bit 0 no byte copied, bits 10-22 pool offset/16 of the constant, bit 23 a constant follows,
+ * bits 24-30 bytes appended} | pool).  kx_df_pending: what slot j (0 = oldest) of product state `state` still owes, per leaf
+ * of its SST state: copy | path-constant id << 1 (n_out = 1: the same for every leaf) — the host evaluates these at the end
+ * leaf to write a shard's last K steps.  Returns 0, KX_E_BLOB, or KX_E_ARG (no such stage / state / slot). */
+typedef struct kx_df_info {
+  uint32_t available;      /* 1: the stage has a delayed form and the engine takes it */
+  uint32_t delay;          /* K */
+  uint32_t nstates;        /* product states (the dead and the escape row follow them in the image) */
+  uint32_t nclasses;
+  uint32_t image_bytes, off_pool, start_handle, dead_handle, escape_handle;
+  uint32_t transitions, escapes;               /* over the whole table */
+  uint32_t transitions_start, escapes_start;   /* over the part reachable from the program's start state */
+  char reason[96];         /* why not, if available == 0 */
+} kx_df_info;
+int kx_df_describe(const void* blob, size_t blob_len, uint32_t stage, kx_df_info* info, void* image, size_t image_cap);
+int kx_df_pending(const void* blob, size_t blob_len, uint32_t stage, uint32_t state, uint32_t slot, uint32_t* sst_state,
+                  uint32_t* kinds, uint32_t* n_out);
+/* of a loaded program: 0 the stage has no delayed form, 1 it runs on it, 2 it had one and a shard gave it up (escape) */
+int kx_stage_delayed_form(const kx_program* prog, uint32_t stage);
+
 /* Whole program (all pipeline stages) over one device-resident input.
  * d_out may be NULL with cap 0 to query the exact output size (returned in
  * *out_len with KX_E_CAPACITY).  Blocks until the result is complete. */

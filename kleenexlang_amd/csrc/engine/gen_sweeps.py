@@ -457,7 +457,145 @@ def main2(out):
             '"memory"')
 
 
+# ------------------------------------------------------------------------------------------------ delayed form (round 5)
+# Entries of the delayed form's table are 8 bytes {lo, hi} (kx_dfkernels.inc), read with one ds_read_b64 into a register PAIR;
+# inline-asm operands cannot name the halves of a pair, so the sequences below use fixed registers for them (listed as clobbers).
+DF_RUN_E = (("v100", "v101"), ("v102", "v103"))
+DF_WALK_E = {"A": (("v116", "v117"), ("v118", "v119")), "B": (("v120", "v121"), ("v122", "v123"))}
+
+
+def dfrun1():
+    """k_dforward's piece: one chain of 64 product transitions from handle h; sum = bytes the steps write (entry hi, byte 3).
+    mid / lenA = state and sum after 32 steps.  Per byte: 1 SDWA byte extract, 1 ds_read_u8 (class*8), 1 SDWA add on the chain,
+    1 ds_read_b64, 1 SDWA add for the length."""
+    L = []
+    ap = L.append
+    E = DF_RUN_E
+    pair = lambda k: "%s[%s:%s]" % ("v", E[k][0][1:], E[k][1][1:])
+    def cls_issue(tt):
+        ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (tt >> 2, SD, tt & 3))
+        ap("ds_read_u8 %%[c%d], %%[x]" % (tt % 3))
+    for tt in (0, 1, 2):
+        cls_issue(tt)
+    ap("s_waitcnt lgkmcnt(2)")
+    ap("v_add_u32 %[x], %[h], %[c0]")
+    ap("ds_read_b64 %s, %%[x]" % pair(0))
+    for j in range(64):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 3 < 64:
+            cls_issue(j + 3)
+        ap("s_waitcnt lgkmcnt(%d)" % (1 if j + 3 < 64 else 0))
+        if j + 1 < 64:
+            ap("v_add_u32_sdwa %%[x], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (E[cur][0], (j + 1) % 3, SD))
+            ap("ds_read_b64 %s, %%[x]" % pair(nxt))
+        ap("v_add_u32_sdwa %%[sum], %%[sum], %s %s src0_sel:DWORD src1_sel:BYTE_3" % (E[cur][1], SD))
+        if j == 31:
+            ap("v_and_b32 %%[mid], 0xffff, %s" % E[cur][0])
+            ap("v_mov_b32 %[lenA], %[sum]")
+        if j == 63:
+            ap("v_and_b32 %%[h], 0xffff, %s" % E[cur][0])
+    return L
+
+
+def dfwalk2(K, xjob=False):
+    """k_demit's fused walk for delay K: chain A = steps 0..31 from (hA, oA), chain B = steps 32..63 from (hB, oB); step s reads the
+    class of input byte s, takes the product transition, and places what the entry says: input byte s-K (if the entry copies) at
+    the cursor, a job for the constant (if one follows), cursor += bytes appended.  Job noting is k_emit's branch-free form
+    (piece_sweep2b): rank among the lanes with a constant, slot address, -1 for lanes without one, one store."""
+    L = []
+    ap = L.append
+    base = {"A": 0, "B": 32}
+    E = DF_WALK_E
+    pair = lambda ch, k: "v[%s:%s]" % (E[ch][k][0][1:], E[ch][k][1][1:])
+    def cls_issue(ch, t, slot):
+        ap("v_lshlrev_b32_sdwa %%[x%s], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (ch, t >> 2, SD, t & 3))
+        ap("ds_read_u8 %%[c%s%d], %%[x%s]" % (ch, slot, ch))
+    twof = {"A": None, "B": None}
+    ap("s_setprio 3")
+    for d in (0, 1):
+        for ch in "AB":
+            cls_issue(ch, base[ch] + d, d)
+    ap("s_waitcnt lgkmcnt(2)")
+    for ch in "AB":
+        ap("v_add_u32 %%[a%s0], %%[h%s], %%[c%s0]" % (ch, ch, ch))
+        ap("ds_read_b64 %s, %%[a%s0]" % (pair(ch, 0), ch))
+    for j in range(32):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 2 < 32:
+            for ch in "AB":
+                cls_issue(ch, base[ch] + j + 2, (j + 2) % 3)
+        # in flight, oldest first: [previous step's 2 byte stores + 2 job stores], class j+1 (2), entry j (2), class j+2 (2, if issued):
+        # wait until the entries of step j are in
+        ap("s_waitcnt lgkmcnt(%d)" % (2 if j == 0 else 6 if j + 2 < 32 else 4))
+        if j + 1 < 32:
+            for ch in "AB":
+                ap("v_add_u32_sdwa %%[a%s%d], %s, %%[c%s%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (ch, nxt, E[ch][cur][0], ch, (j + 1) % 3, SD))
+                ap("ds_read_b64 %s, %%[a%s%d]" % (pair(ch, nxt), ch, nxt))
+        for ch in "AB":
+            t = base[ch] + j
+            so = t - K
+            hi, o, a, x = E[ch][cur][1], "%%[o%s]" % ch, "%%[a%s%d]" % (ch, cur), "%%[x%s]" % ch
+            if so >= 0:
+                wreg, by = "%%[w%d]" % (so >> 2), so & 3
+            else:
+                wreg, by = "%[wp]", (4 + so) & 3
+            if by in (1, 3) and twof[ch] != wreg:
+                # (a shifted copy of the dword serves its bytes 1 and 3)
+                ap("v_lshrrev_b32 %%[tw%s], 8, %s" % (ch, wreg))
+                twof[ch] = wreg
+            src = "%%[tw%s]" % ch if by in (1, 3) else wreg
+            wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % hi)
+            ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))              # the job word: cursor << 16 | entry address
+            ap("v_lshl_or_b32 %s, %s, 31, %s" % (x, hi, o))             # where the copied byte goes (out of range if nothing is copied)
+            ap("v_add_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, hi, SD))
+            ap("%s %s, %s" % (wr, x, src))
+            if xjob:
+                # (experiment: only the lanes with a constant take part in the job store)
+                ap("s_and_saveexec_b64 %[sv], vcc")
+                ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % hi)
+                ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (hi, hi))
+                ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (hi, hi))
+                ap("v_min_u32 %s, %%[jlim], %s" % (hi, hi))
+                ap("ds_write_b32 %s, %s" % (hi, a))
+                ap("s_mov_b64 exec, %[sv]")
+            else:
+                ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % hi)
+                ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (hi, hi))
+                ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (hi, hi))
+                ap("v_min_u32 %s, %%[jlim], %s" % (hi, hi))
+                ap("v_cndmask_b32_e32 %s, -1, %s, vcc" % (hi, hi))
+                ap("ds_write_b32 %s, %s" % (hi, a))
+            ap("s_bcnt1_i32_b64 %[st], vcc")
+            ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
+    ap("s_setprio 0")
+    return L
+
+
+def main7(out):
+    tmp = ["c0", "c1", "c2", "x"]
+    clob = ", ".join('"%s"' % r for pr in DF_RUN_E for r in pr)
+    emit_fn(out, "piece_dfrun1",
+            "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid, uint32_t& lenA, uint32_t& sum",
+            "uint32_t " + ", ".join(tmp) + ";",
+            dfrun1(),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[lenA] "=&v"(lenA)', '[h] "+v"(h)', '[sum] "+v"(sum)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
+            '"memory", ' + clob)
+    tmp = ["cA0", "cA1", "cA2", "cB0", "cB1", "cB2", "xA", "xB", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
+    clob = ", ".join('"%s"' % r for ch in "AB" for pr in DF_WALK_E[ch] for r in pr)
+    for K, xj in ((1, False), (2, False), (2, True)):
+        emit_fn(out, "piece_dfwalk2_k%d%s" % (K, "x" if xj else ""),
+                "const uint32_t (&w)[16], uint32_t wp, uint32_t hA, uint32_t& oA, uint32_t hB, uint32_t& oB, uint32_t& jb, uint32_t jlim",
+                "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv;",
+                dfwalk2(K, xj),
+                ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[st] "=&s"(st)', '[sv] "=&s"(sv)', '[oA] "+v"(oA)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
+                ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[wp] "v"(wp)', '[hA] "v"(hA)', '[hB] "v"(hB)', '[jlim] "s"(jlim)'],
+                '"vcc", "scc", "memory", ' + clob)
+
+
 if __name__ == "__main__":
     main()
     main2(sys.stdout)
     main6(sys.stdout)
+    main7(sys.stdout)

@@ -66,6 +66,13 @@ class KxConfig(ctypes.Structure):
                 ("collect_timing", ctypes.c_uint32), ("phase", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
 
 
+class KxDfInfo(ctypes.Structure):
+    """include/kxhip.h::kx_df_info — the delayed form of one stage."""
+    _fields_ = [(k, ctypes.c_uint32) for k in ("available", "delay", "nstates", "nclasses", "image_bytes", "off_pool", "start_handle",
+                                               "dead_handle", "escape_handle", "transitions", "escapes", "transitions_start",
+                                               "escapes_start")] + [("reason", ctypes.c_char * 96)]
+
+
 class KxFwdSummary(ctypes.Structure):
     _fields_ = [("synced", ctypes.c_uint32), ("end_state", ctypes.c_uint32),
                 ("head_len", ctypes.c_uint64), ("fail_pos", ctypes.c_uint64)]
@@ -127,6 +134,9 @@ def load_engine():
         lib.kx_num_stages.argtypes = [vp]
         lib.kx_num_stages.restype = u32
         lib.kx_stage_has_actions.argtypes = [vp, u32]
+        lib.kx_stage_delayed_form.argtypes = [vp, u32]
+        lib.kx_df_describe.argtypes = [ctypes.c_char_p, sz, u32, ctypes.POINTER(KxDfInfo), vp, sz]
+        lib.kx_df_pending.argtypes = [ctypes.c_char_p, sz, u32, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
         lib.kx_run_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(KxStats), vp]
         lib.kx_run_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz),
                                     ctypes.POINTER(KxStats)]
@@ -285,6 +295,33 @@ def validate_blob(blob):
     blob = bytes(blob)
     if lib.kx_validate(blob, len(blob)):
         raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+
+
+def df_describe(blob, stage=0, with_image=True):
+    """The delayed form of a stage, built on the host (no device needed): (KxDfInfo, table image bytes or None)."""
+    lib = load_engine()
+    blob = bytes(blob)
+    info = KxDfInfo()
+    if lib.kx_df_describe(blob, len(blob), stage, ctypes.byref(info), None, 0):
+        raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+    img = None
+    if with_image and info.image_bytes:
+        buf = ctypes.create_string_buffer(info.image_bytes)
+        lib.kx_df_describe(blob, len(blob), stage, ctypes.byref(info), buf, info.image_bytes)
+        img = buf.raw
+    return info, img
+
+
+def df_pending(blob, stage, state, slot):
+    """(SST state, [copy | path-constant id << 1 per leaf, or one value]) of a product state's pending slot."""
+    lib = load_engine()
+    blob = bytes(blob)
+    kinds = (ctypes.c_uint32 * KX_MAX_LEAVES)()
+    n = ctypes.c_uint32()
+    q = ctypes.c_uint32()
+    if lib.kx_df_pending(blob, len(blob), stage, state, slot, ctypes.byref(q), kinds, ctypes.byref(n)):
+        raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+    return q.value, list(kinds[:n.value])
 
 
 class KexcIlProgram(ctypes.Structure):
@@ -471,6 +508,10 @@ class Program:
     # sharded protocol (one shard per rank); thin wrappers, see include/kxhip.h
     def stage_has_actions(self, stage):
         return bool(self._lib.kx_stage_has_actions(self._h, stage))
+
+    def stage_delayed_form(self, stage=0):
+        """0: the stage has no delayed form; 1: it runs on it; 2: a shard gave it up (an undecided context), later shards run the general engine."""
+        return int(self._lib.kx_stage_delayed_form(self._h, stage))
 
     def run_sharded(self, rank, world, gather, d_in, n, d_out, cap, stream=None):
         """kx_run_sharded: this rank's shard through every stage, the boundary hand-off done by the library through `gather`

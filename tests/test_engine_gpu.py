@@ -12,6 +12,17 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["delayed", "general"])
+def engine_mode(request, monkeypatch):
+    """Every test of this file runs twice: with the delayed form where a stage has one (round 5, the default), and with the general
+    engine only (KX_DF=0: forward / backward / sweep) — the delayed form's fall-back, and the only engine of programs without one."""
+    if request.param == "general":
+        monkeypatch.setenv("KX_DF", "0")
+    else:
+        monkeypatch.delenv("KX_DF", raising=False)
+    return request.param
+
+
 def both(blob, data, **cfg):
     """(engine result, oracle result) where a result is bytes or ('fail', pos)."""
     try:
@@ -377,14 +388,15 @@ def test_rccl_boundary_handoff_two_and_four_ranks_on_one_device():
         assert line["output_checked_bit_exact"] is True and line["output_bytes_checked"] == line["config"]["output_bytes_total"]
 
 
-def test_layout_follows_the_constants_per_piece_of_earlier_shards(tmp_path):
-    """Round 4: a stage that qualifies keeps two table images — vote-and-rank job noting and the job-stride layout with counted job
+def test_layout_follows_the_constants_per_piece_of_earlier_shards(tmp_path, monkeypatch):
+    """(General engine: the delayed form has one layout.)  Round 4: a stage that qualifies keeps two table images — vote-and-rank job noting and the job-stride layout with counted job
     slots — and every shard (a run of the program object, a window of a streamed input) picks the one that suits the constants per
     piece the shards before it held: iso_datetime_to_json (21 per piece) moves to the job-stride layout after its first shard,
     apache_log (4) stays.  Same bytes either way: consecutive runs on one Program, and a produced binary streaming its input in
     small windows (the switch happens in mid-stream)."""
     import subprocess
     from kleenexlang_amd import build, program_path
+    monkeypatch.setenv("KX_DF", "0")
     for prog, shape in (("iso_datetime_to_json", "datetime"), ("apache_log", "apache_log"), ("csv2json", "csv")):
         blob = blob_of(prog)
         data = workloads.generate(shape, 3 << 20, 21)

@@ -488,16 +488,18 @@ def dfrun1():
         if j + 1 < 64:
             ap("v_add_u32_sdwa %%[x], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (E[cur][0], (j + 1) % 3, SD))
             ap("ds_read_b64 %s, %%[x]" % pair(nxt))
-        ap("v_add_u32_sdwa %%[sum], %%[sum], %s %s src0_sel:DWORD src1_sel:BYTE_3" % (E[cur][1], SD))
+        # (lo's upper half = bytes appended << 8 | 4 x "a constant follows": the sum's low byte counts the constants, its bits 8.. the bytes)
+        ap("v_add_u32_sdwa %%[sum], %%[sum], %s %s src0_sel:DWORD src1_sel:WORD_1" % (E[cur][0], SD))
         if j == 31:
             ap("v_and_b32 %%[mid], 0xffff, %s" % E[cur][0])
             ap("v_mov_b32 %[lenA], %[sum]")
+            ap("v_and_b32 %[sum], 0xffffff00, %[sum]")   # (32 steps x 4 fit a byte, 64 would not)
         if j == 63:
             ap("v_and_b32 %%[h], 0xffff, %s" % E[cur][0])
     return L
 
 
-def dfwalk2(K, xjob=False):
+def dfwalk2(K, counted=True):
     """k_demit's fused walk for delay K: chain A = steps 0..31 from (hA, oA), chain B = steps 32..63 from (hB, oB); step s reads the
     class of input byte s, takes the product transition, and places what the entry says: input byte s-K (if the entry copies) at
     the cursor, a job for the constant (if one follows), cursor += bytes appended.  Job noting is k_emit's branch-free form
@@ -526,7 +528,8 @@ def dfwalk2(K, xjob=False):
                 cls_issue(ch, base[ch] + j + 2, (j + 2) % 3)
         # in flight, oldest first: [previous step's 2 byte stores + 2 job stores], class j+1 (2), entry j (2), class j+2 (2, if issued):
         # wait until the entries of step j are in
-        ap("s_waitcnt lgkmcnt(%d)" % (2 if j == 0 else 6 if j + 2 < 32 else 4))
+        # (counted slots: a job store of a step in which no lane has a constant may not count — wait as if it had not been issued)
+        ap("s_waitcnt lgkmcnt(%d)" % (2 if j == 0 else (4 if counted else 6) if j + 2 < 32 else (2 if counted else 4)))
         if j + 1 < 32:
             for ch in "AB":
                 ap("v_add_u32_sdwa %%[a%s%d], %s, %%[c%s%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (ch, nxt, E[ch][cur][0], ch, (j + 1) % 3, SD))
@@ -545,27 +548,32 @@ def dfwalk2(K, xjob=False):
                 twof[ch] = wreg
             src = "%%[tw%s]" % ch if by in (1, 3) else wreg
             wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+            if counted:
+                # COUNTED SLOTS: the piece records carry how many constants each half of the piece appends, so every lane owns its job
+                # slots before the walk (a prefix sum in k_demit) and a step with a constant stores its job at the lane's own pointer
+                # — no rank among the lanes, no clamp, no wave-wide counter; only the lanes with a constant take part in the store
+                pp = "%%[p%s]" % ch
+                ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % hi)
+                ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))
+                ap("v_lshl_or_b32 %s, %s, 31, %s" % (x, hi, o))
+                ap("v_add_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, hi, SD))
+                ap("%s %s, %s" % (wr, x, src))
+                ap("s_and_saveexec_b64 %[sv], vcc")
+                ap("ds_write_b32 %s, %s" % (pp, a))
+                ap("s_mov_b64 exec, %[sv]")
+                ap("v_add_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_2" % (pp, pp, E[ch][cur][0], SD))
+                continue
             ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % hi)
             ap("v_lshl_or_b32 %s, %s, 16, %s" % (a, o, a))              # the job word: cursor << 16 | entry address
             ap("v_lshl_or_b32 %s, %s, 31, %s" % (x, hi, o))             # where the copied byte goes (out of range if nothing is copied)
             ap("v_add_u32_sdwa %s, %s, %s %s src0_sel:DWORD src1_sel:BYTE_3" % (o, o, hi, SD))
             ap("%s %s, %s" % (wr, x, src))
-            if xjob:
-                # (experiment: only the lanes with a constant take part in the job store)
-                ap("s_and_saveexec_b64 %[sv], vcc")
-                ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % hi)
-                ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (hi, hi))
-                ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (hi, hi))
-                ap("v_min_u32 %s, %%[jlim], %s" % (hi, hi))
-                ap("ds_write_b32 %s, %s" % (hi, a))
-                ap("s_mov_b64 exec, %[sv]")
-            else:
-                ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % hi)
-                ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (hi, hi))
-                ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (hi, hi))
-                ap("v_min_u32 %s, %%[jlim], %s" % (hi, hi))
-                ap("v_cndmask_b32_e32 %s, -1, %s, vcc" % (hi, hi))
-                ap("ds_write_b32 %s, %s" % (hi, a))
+            ap("v_mbcnt_lo_u32_b32 %s, vcc_lo, 0" % hi)
+            ap("v_mbcnt_hi_u32_b32 %s, vcc_hi, %s" % (hi, hi))
+            ap("v_lshl_add_u32 %s, %s, 2, %%[jb]" % (hi, hi))
+            ap("v_min_u32 %s, %%[jlim], %s" % (hi, hi))
+            ap("v_cndmask_b32_e32 %s, -1, %s, vcc" % (hi, hi))
+            ap("ds_write_b32 %s, %s" % (hi, a))
             ap("s_bcnt1_i32_b64 %[st], vcc")
             ap("s_lshl2_add_u32 %[jb], %[st], %[jb]")
     ap("s_setprio 0")
@@ -584,13 +592,13 @@ def main7(out):
             '"memory", ' + clob)
     tmp = ["cA0", "cA1", "cA2", "cB0", "cB1", "cB2", "xA", "xB", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
     clob = ", ".join('"%s"' % r for ch in "AB" for pr in DF_WALK_E[ch] for r in pr)
-    for K, xj in ((1, False), (2, False), (2, True)):
-        emit_fn(out, "piece_dfwalk2_k%d%s" % (K, "x" if xj else ""),
-                "const uint32_t (&w)[16], uint32_t wp, uint32_t hA, uint32_t& oA, uint32_t hB, uint32_t& oB, uint32_t& jb, uint32_t jlim",
-                "uint32_t " + ", ".join(tmp) + ", st; unsigned long long sv;",
-                dfwalk2(K, xj),
-                ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[st] "=&s"(st)', '[sv] "=&s"(sv)', '[oA] "+v"(oA)', '[oB] "+v"(oB)', '[jb] "+s"(jb)'],
-                ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[wp] "v"(wp)', '[hA] "v"(hA)', '[hB] "v"(hB)', '[jlim] "s"(jlim)'],
+    for K in (1, 2):
+        emit_fn(out, "piece_dfwalk2c_k%d" % K,
+                "const uint32_t (&w)[16], uint32_t wp, uint32_t hA, uint32_t& oA, uint32_t hB, uint32_t& oB, uint32_t& pA, uint32_t& pB",
+                "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
+                dfwalk2(K, counted=True),
+                ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[oA] "+v"(oA)', '[oB] "+v"(oB)', '[pA] "+v"(pA)', '[pB] "+v"(pB)'],
+                ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[wp] "v"(wp)', '[hA] "v"(hA)', '[hB] "v"(hB)'],
                 '"vcc", "scc", "memory", ' + clob)
 
 

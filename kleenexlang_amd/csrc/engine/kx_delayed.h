@@ -222,6 +222,8 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
         const Tr& t = trans[i][c];
         if (t.next == -1) lo = out.deadh; else if (t.next == -2) lo = out.esch; else { lo = out.handleOf((uint32_t)t.next); hi = entryHi(t.emit); }
       }
+      // the upper half of lo repeats what the measuring pass adds up in ONE add: bytes appended << 8 | 4 x "a constant follows"
+      lo |= (hi & 0xFF000000u) | (((hi >> 23) & 1u) << 18);
       rows[((size_t)i * C + c) * 2] = lo; rows[((size_t)i * C + c) * 2 + 1] = hi;
     }
   memcpy(ib + off_pool, in.apool, in.apool_bytes);

@@ -28,6 +28,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # with today's instruction counts per 4 KiB (k_forward + k_backlen + k_emit, SQ counters of profiles/r04z_*) and the
 # measured ≈ 3.7 SIMD-cycles per wave-instruction the three kernels cannot run faster than this fraction of 8 TB/s.
 ISSUE_BOUND_FRAC = {"apache_log": 0.101}
+# the delayed form (round 5): k_dforward + k_demit issue ~1 270 vector instructions per 4 KiB (profiles/r05z_sq_counters.json): at one
+# VALU issue per SIMD every 4 cycles that is 1 270 CU-cycles per 4 KiB = 1.98 TB/s of input
+ISSUE_BOUND_FRAC_DELAYED = {"apache_log": 0.248}
 
 
 def cpu_baseline(program, base, sample_bytes):
@@ -231,11 +234,18 @@ def main():
         dom = max(kern, key=kern.get)
         ratio = olen / float(n_local)
         ksum = sum(kern.values())
+        # which engine ran: the delayed form (round 5: one forward pass + one fused placing walk, kernels k_dforward / k_dlen / k_demit)
+        # or the general engine (forward, backward, sweep: k_forward / k_backlen / k_resolve.. / k_emit)
+        df_state = prog.stage_delayed_form(0)
+        delayed = df_state == 1
+        kname = ({"forward": "k_dforward", "resolve": "k_dlen", "emit": "k_demit"}.get(dom, "k_" + dom)) if delayed else "k_" + dom
         # algorithmic bytes = 1 B read per input byte; `achieved` = input bytes of one launch ÷ the dominant
         # kernel's mean launch duration (HIP events on the engine's stream, recorded by the engine around each kernel).
         achieved = n_local / (kern[dom] / 1e3) / 1e9 if kern[dom] > 0 else 0.0
         # the same kernel's own traffic (what it must read and write per input byte) — NOT the roofline fraction
         alg = {"sync": 0.0, "forward": 1.0, "head": 0.0, "backlen": 1.0, "resolve": 0.0, "emit": 1.0 + ratio}
+        if delayed:   # (16-byte piece records per 64 input bytes: written by the forward pass, read by the placing walk)
+            alg = {"sync": 0.0, "forward": 1.25, "head": 0.0, "backlen": 0.0, "resolve": 0.0, "emit": 1.25 + ratio}
         traffic, traffic_note = None, "no PMC passes for this build"
         try:   # HBM bytes per launch of the dominant kernel from the PMC passes — only if they were taken with THIS engine build
             import glob
@@ -243,7 +253,7 @@ def main():
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")), reverse=True):
                 tj = json.load(open(f))
                 if tj.get("engine_sha") == kbuild.engine_sha() and tj.get("program", "apache_log") == a.program and abs(tj["input_bytes"] - n_local) < (1 << 20):
-                    traffic = tj["per_launch"]["k_" + dom]["total"]
+                    traffic = tj["per_launch"][kname]["total"]
                     traffic_note = os.path.basename(f)
                     break
         except Exception as e:   # noqa: BLE001
@@ -257,11 +267,13 @@ def main():
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
                        "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "output_bytes_total": total_out,
                        "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
+                       "engine": ("delayed form (forward transducer with fixed delay, no backward pass; DESIGN.md §2e)" if delayed else
+                                  "general (forward, backward, sweep)" + (" after the delayed form met an undecided context" if df_state == 2 else "")),
                        "parallelism": "shard%d" % world, "boundary_backend": (a.backend if use_dist else None),
                        "boundary_driver": (None if not use_dist else "python (sharded.py over torch.distributed)" if a.py_driver else "kx_run_sharded (C, own RCCL communicator)"),
                        "boundary_ms_per_step_rank0": (round(totals["boundary_ms"] / a.steps, 4) if comm is not None else None),
                        "single_device_validation": bool(a.single_device)},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_input_byte": 1.0},
             # How far `frac` is from what is possible: a perfect single-pass engine moves 1 B in + r B out per input
@@ -269,10 +281,11 @@ def main():
             # bounds of the WHOLE PATH (compare `whole_path.frac_of_hbm_peak`), stated as fractions of the 8 TB/s read roofline.
             "ceilings": {"out_over_in": round(ratio, 4),
                          "single_pass_hbm_bound_frac": round(6300.0 / (1.0 + ratio) / HBM_PEAK_GBPS, 4),
-                         "this_design_hbm_bound_frac": round(6300.0 / (3.0 + ratio + 3.0 / 16.0) / HBM_PEAK_GBPS, 4),
-                         "this_design_issue_bound_frac": ISSUE_BOUND_FRAC.get(a.program),
-                         "note": "fractions of 8 TB/s; north_star's 40 % is above the single-pass HBM bound for this output ratio; the issue bound is "
-                                 "instructions per 4 KiB x ~3.7 SIMD-cycles each (measured, DESIGN.md §4), the limit this engine actually runs into"},
+                         "this_design_hbm_bound_frac": round(6300.0 / ((2.5 if delayed else 3.0 + 3.0 / 16.0) + ratio) / HBM_PEAK_GBPS, 4),
+                         "this_design_issue_bound_frac": (ISSUE_BOUND_FRAC_DELAYED if delayed else ISSUE_BOUND_FRAC).get(a.program),
+                         "note": "fractions of 8 TB/s; north_star's 40 % is above the single-pass HBM bound for this output ratio; this design reads the "
+                                 "input twice (delayed form; three times on the general engine) plus its piece records; the issue bound is vector "
+                                 "instructions per 4 KiB x 4 SIMD-cycles each (one VALU issue per SIMD and 4 cycles, DESIGN.md §4) at today's counts"},
             "whole_path": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,
                            "frac_of_hbm_peak": round(n_local / (ksum / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if ksum else None},
             "dominant_kernel_own_traffic": {"bytes_per_input_byte": round(alg[dom], 4),

@@ -175,7 +175,8 @@ typedef struct kx_sharded_result {
   float boundary_ms;   /* wall time this rank spent inside the all-gathers (waiting for the slowest rank included) */
   kx_stats stats;      /* kernel times summed over the stages; fail_pos / fail_stage on a match error */
 } kx_sharded_result;
-/* (collective return code: every record of the three exchanges carries the sender's status, so a local failure — out of memory,
+/* (collective return code: every record of the exchanges carries the sender's status and one more status word follows the last
+ *  stage's emit, so a local failure — out of memory,
  *  a HIP error — ends the call on EVERY rank instead of leaving the others inside an all-gather) */
 int kx_run_sharded(kx_program* prog, int rank, int world, kx_allgather_fn ag, void* ag_ctx, const void* d_in, size_t n,
                    void* d_out, size_t cap, kx_sharded_result* res, void* stream);

@@ -230,7 +230,7 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
   int rc = 0;
   for (uint32_t st = 0; st < ns; ++st) {
     kx_shard* s = nullptr;
-    local(kx_shard_begin(p, st, cur, curn, rank == 0, rank == world - 1, stream, &s));
+    if (!err) local(kx_shard_begin(p, st, cur, curn, rank == 0, rank == world - 1, stream, &s));   // (not on the half-written buffer of a stage whose emit failed)
     struct EndShard { kx_shard* s; kx_stats* acc; ~EndShard() {
       if (!s) return;
       kx_stats ss; kx_shard_stats(s, &ss);
@@ -313,9 +313,15 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
       res->out_len = ol; res->out_offset = off; res->total_out = total;
     }
     // (a failure of the emit itself is local again: it is reported by the next stage's first exchange, or — on the last
-    //  stage — by this rank's return code alone; no rank waits for another after this point)
-    rc = kx_shard_emit(s, dst, dcap);
-    if (rc) { if (st + 1 == ns) { res->boundary_ms = (float)boundary; return rc; } local(rc); }
+    //  stage — by one more exchange of status words, so that the return code is collective for the whole call and no caller
+    //  assembles a truncated output from the ranks that succeeded)
+    if (!err) local(kx_shard_emit(s, dst, dcap));
+    if (st + 1 == ns && world > 1) {
+      LenMsg mine{0, err ? 1u : 0u, 0u};
+      rc = gather(&mine, lens.data(), sizeof(LenMsg));
+      if (rc) return rc;
+      if ((rc = collective(lens))) return rc;
+    } else if (st + 1 == ns && err) { res->boundary_ms = (float)boundary; return sErr(err, err_msg); }
     cur = dst; curn = ol;
   }
   res->stats.in_bytes = n; res->stats.out_bytes = res->out_len;

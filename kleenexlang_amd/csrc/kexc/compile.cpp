@@ -390,6 +390,15 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
       std::vector<size_t> tbl_at(P.ntables, 0);
       for (uint32_t k = 0, at = 0; k < P.ntables; ++k) { if (P.tbl_width[k] > 8) bad("table digits wider than 8"); tbl_at[k] = at; at += 256 * P.tbl_width[k]; }
       auto tblEntry = [&](uint32_t k, int sym) { return std::string((const char*)P.tbl_data + tbl_at[k] + (size_t)sym * P.tbl_width[k], P.tbl_width[k]); };
+      // what a table entry becomes when it is written out as a constant: in a stage with register actions the output is a token
+      // stream whose escape byte is FF, so a table value FF leaves as FF FF like any other data byte (kxp_format.h)
+      auto tblOut = [&](uint32_t k, int sym) {
+        std::string v = tblEntry(k, sym);
+        if (!P.has_actions) return v;
+        std::string e;
+        for (char ch : v) { e += ch; if ((uint8_t)ch == KXP_ESC) e += ch; }
+        return e;
+      };
       bool uses_tables = false;
       for (uint32_t a = 0; a < P.nactions; ++a) {
         if (P.action_off[a + 1] < P.action_off[a]) bad("action offsets out of order");
@@ -462,7 +471,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
                 auto it = actMemo.find({t.act[o], key});
                 if (it == actMemo.end()) {
                   std::vector<MicroOp> ops = t.actions[t.act[o]];
-                  for (auto& m : ops) if (m.op == 4) { m.arg = internC(tblEntry(m.arg, rep[c])); m.op = 1; }
+                  for (auto& m : ops) if (m.op == 4) { m.arg = internC(tblOut(m.arg, rep[c])); m.op = 1; }
                   t.actions.push_back(ops);
                   it = actMemo.emplace(std::make_pair(t.act[o], key), (uint32_t)t.actions.size() - 1).first;
                 }
@@ -483,7 +492,7 @@ int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(cons
                     const uint32_t tb = btab[(size_t)row * ML + l];
                     if (tb != 0xFFFFFFFFu) {
                       if ((e >> 9) >= P.npconsts) bad("backward entry out of range");
-                      e = (e & 0x1FF) | (internP(tblEntry(tb, rep[c]) + t.pconsts[e >> 9]) << 9);
+                      e = (e & 0x1FF) | (internP(tblOut(tb, rep[c]) + t.pconsts[e >> 9]) << 9);
                     }
                     t.back.push_back(e);
                   }

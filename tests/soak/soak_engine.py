@@ -7,7 +7,7 @@ from kleenexlang_amd import MatchError, Program, CompileError
 from oracle import oracle
 
 STAR = False
-t0 = time.time(); n = bad = 0; acc = 0; outb = 0
+t0 = time.time(); n = bad = 0; acc = 0; outb = 0; dfs = [0, 0, 0]   # runs by what the stage ran on: general / delayed form / fell back
 for seed in range(int(os.environ.get("SOAK_LO", 300)), int(os.environ.get("SOAK_HI", 700))):
     src = randprog.program(seed)
     if STAR:   # make the whole program repeatable so that long accepted inputs exist: main := (old main "|")* with old main renamed
@@ -52,6 +52,7 @@ for seed in range(int(os.environ.get("SOAK_LO", 300)), int(os.environ.get("SOAK_
             except MatchError as e:
                 got = ("fail", e.pos)
             n += 1
+            dfs[p.stage_delayed_form(0)] += 1
             if not isinstance(want, tuple): acc += 1; outb += len(want)
             if got != want:
                 bad += 1
@@ -60,4 +61,4 @@ for seed in range(int(os.environ.get("SOAK_LO", 300)), int(os.environ.get("SOAK_
         p.close()
     if time.time() - t0 > 500:
         break
-print("accepted", acc, "output bytes", outb); print("runs", n, "mismatches", bad, "seeds up to", seed, "time", round(time.time() - t0))
+print("accepted", acc, "output bytes", outb, "runs on the general engine / the delayed form / after a fall-back", dfs); print("runs", n, "mismatches", bad, "seeds up to", seed, "time", round(time.time() - t0))

@@ -177,6 +177,27 @@ def mixed_expected(data):
     return bytes(c - 32 if c in b"abcd" else (ord(";") if c == ord(",") else c) for c in data)
 
 
+def test_table_value_ff_in_a_stage_with_actions_is_escaped(tmp_path):
+    """a stage with register actions takes no table atoms — its AppendTblI entries are written out as constants — and
+    its output is a token stream whose escape byte is FF.  A table value FF must therefore leave as FF FF (the byte FF), not as
+    the start of a Push / Pop / Write token: d -> FF here, and the replayed output holds the single byte."""
+    prog = mixed_copy_and_table_program()
+    table = np.array(prog["tbl_data"], dtype=np.uint8)
+    table[ord("d")] = 0xFF
+    prog["tbl_data"] = table
+    prog["has_actions"], prog["action_regs"] = 1, 1
+    out = tmp_path / "ff.kxp"
+    assert emit_pipeline([prog], srcout=out) == 0
+    blob = out.read_bytes()
+    st = kxp.parse(blob)[0]
+    assert st.tables is None and st.actions & 1                      # written out, and still an action stage
+    assert b"\xff\xff" in bytes(st.pool) and b"\xff\xff" in bytes(st.cpool)
+    for data in (b"d", b"abcd,xyz", b"dd,dxd", b"ddddddddcba" * 20):
+        want = bytes(0xFF if c == ord("d") else c - 32 if c in b"abc" else (ord(";") if c == ord(",") else c) for c in data)
+        for pf in (False, True):
+            assert oracle.run(blob, data, path_form=pf) == want, (data, pf)
+
+
 def test_plain_copies_beside_table_steps(tmp_path):
     out = tmp_path / "mixed.kxp"
     assert emit_pipeline([mixed_copy_and_table_program()], srcout=out) == 0

@@ -460,7 +460,7 @@ def main2(out):
 # ------------------------------------------------------------------------------------------------ delayed form (round 5)
 # Entries of the delayed form's table are 8 bytes {lo, hi} (kx_dfkernels.inc), read with one ds_read_b64 into a register PAIR;
 # inline-asm operands cannot name the halves of a pair, so the sequences below use fixed registers for them (listed as clobbers).
-DF_RUN_E = (("v100", "v101"), ("v102", "v103"))
+DF_RUN_E = (("v76", "v77"), ("v78", "v79"))   # (below 80: k_dforward keeps 6 waves per SIMD)
 DF_WALK_E = {"A": (("v116", "v117"), ("v118", "v119")), "B": (("v120", "v121"), ("v122", "v123"))}
 
 

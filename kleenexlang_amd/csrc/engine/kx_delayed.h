@@ -45,6 +45,11 @@ struct DfState { uint32_t q; std::vector<Slot> pend; };
 struct DfBuild {
   uint32_t K = 0, C = 0, nP = 0;
   std::vector<uint32_t> img;               // LDS image: [class*8 u8[256] | rows (nP + 2) x C x {lo, hi} | pool]
+  // pool: every path constant FOUR times — copy s = the constant from its byte s on, zero-padded to plen = (length + 15) & ~15
+  // bytes, the copies one behind the other from a 16-byte boundary — so that k_demit can store the part of a constant behind the
+  // next 4-byte boundary of its destination as ALIGNED DWORDS fetched with one aligned 16-byte read (copy s, s = bytes up to
+  // that boundary); an entry names copy 0
+  std::vector<uint32_t> pool_off;          // [npc] offset of copy 0 inside the pool
   uint32_t off_pool = 0, deadh = 0, esch = 0, starth = 0;
   std::vector<uint16_t> start_of_state;    // [nstates] handle of (q, nothing pending); 0xFFFF = not in the table
   std::vector<DfState> states;             // host copy: original state and pending functions of every product state
@@ -97,8 +102,9 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   };
   const size_t row_bytes = (size_t)C * 8;
   size_t maxP = (65536 - DF_OFF_ROWS) / row_bytes;
-  if (image_budget > DF_OFF_ROWS + in.apool_bytes + 3 * row_bytes) {
-    const size_t byb = (image_budget - DF_OFF_ROWS - in.apool_bytes) / row_bytes;
+  const size_t pool_est = 4 * (size_t)in.apool_bytes + 64;   // (four copies of every constant)
+  if (image_budget > DF_OFF_ROWS + pool_est + 3 * row_bytes) {
+    const size_t byb = (image_budget - DF_OFF_ROWS - pool_est) / row_bytes;
     if (byb < maxP) maxP = byb;
   } else return "no room for the table";
   if (maxP < 4) return "no room for the table";
@@ -201,16 +207,30 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   // image
   const size_t rows_end = DF_OFF_ROWS + (size_t)(nP + 2) * row_bytes;
   const size_t off_pool = (rows_end + 15) & ~(size_t)15;
-  if (off_pool + in.apool_bytes > 65536 + 32768) return "image too large";
+  std::vector<uint8_t> pool;
+  out.pool_off.assign(in.npc, 0);
+  for (uint32_t pc = 0; pc < in.npc; ++pc) {
+    if (canon[pc] != pc) { out.pool_off[pc] = out.pool_off[canon[pc]]; continue; }
+    const uint32_t L = clen[pc], plen = (L + 15) & ~15u;
+    out.pool_off[pc] = (uint32_t)pool.size();
+    for (uint32_t sft = 0; sft < 4; ++sft) {
+      const size_t at = pool.size();
+      pool.resize(at + plen, 0);
+      if (sft < L) memcpy(&pool[at], in.pcpool + in.pcoff[pc] + sft, L - sft);
+    }
+  }
+  pool.resize(pool.size() + 32, 0);   // (reads of 16 bytes behind the last copy stay inside)
+  if ((pool.size() >> 4) >= (1u << 13)) return "constant pool too large";
+  if (off_pool + pool.size() > 65536 + 32768) return "image too large";
   out.off_pool = (uint32_t)off_pool;
-  out.img.assign((off_pool + in.apool_bytes + 3) / 4, 0u);
+  out.img.assign((off_pool + pool.size() + 3) / 4, 0u);
   uint8_t* ib = (uint8_t*)out.img.data();
   for (int b = 0; b < 256; ++b) ib[b] = (uint8_t)(in.cls[b] * 8);
   auto entryHi = [&](Kind k) -> uint32_t {
     const uint32_t copy = k & 1u, pc = k >> 1;
     const uint32_t cl = pc < in.npc ? clen[pc] : 0u;
     uint32_t e = (copy ? 0u : 1u) | ((cl + copy) << 24);
-    if (cl) e |= ((in.apoff[pc] >> 4) << 10) | (1u << 23);
+    if (cl) e |= ((out.pool_off[pc] >> 4) << 10) | (1u << 23);
     return e;
   };
   uint32_t* rows = out.img.data() + DF_OFF_ROWS / 4;
@@ -226,7 +246,7 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
       lo |= (hi & 0xFF000000u) | (((hi >> 23) & 1u) << 18);
       rows[((size_t)i * C + c) * 2] = lo; rows[((size_t)i * C + c) * 2 + 1] = hi;
     }
-  memcpy(ib + off_pool, in.apool, in.apool_bytes);
+  memcpy(ib + off_pool, pool.data(), pool.size());
   return "";
 }
 

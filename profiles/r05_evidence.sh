@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-5 evidence of the tree as it stands (GPU box): the GPU suite, the bench lines of the 10 GiB configurations, rocprofv3 kernel
+# stats + FETCH/WRITE_SIZE of the default bench (collect.sh), SQ counters of the delayed-form kernels (collect_sq_df.sh), the phase
+# timeline of k_demit.   usage: profiles/r05_evidence.sh TAG
+TAG=${1:-r05z}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/gpu_pytest.txt
+for P in apache_log csv2json iso_datetime_to_json thousand_sep; do
+  timeout 300 python bench.py --steps 10 --warmup 2 --program $P $( [ $P = apache_log ] || echo --no-cpu ) > $OUT/bench_$P.json 2> $OUT/bench_$P.err
+done
+KX_DF=0 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu > $OUT/bench_apache_log_general_engine.json 2>> $OUT/bench_apache_log.err
+KX_DEBUG=1 KX_DEBUG_FLAGS=64 timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu 2>&1 | grep "timeline" | tail -1 > $OUT/timeline.txt
+profiles/collect.sh $TAG > $OUT/collect.log 2>&1
+profiles/collect_sq_df.sh $TAG > $OUT/sq.log 2>&1
+tail -3 $OUT/gpu_pytest.txt; tail -3 $OUT/sq.log; cat $OUT/timeline.txt
+for f in $OUT/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1])); print(sys.argv[1].split("/")[-1], d["value"], d["ms_per_step"], d["kernels_ms"], d["roofline"]["frac"], d["output_checked_bit_exact"])
+except Exception as e: print(sys.argv[1], "ERR", e)
+PY
+done

@@ -580,6 +580,58 @@ def dfwalk2(K, counted=True):
     return L
 
 
+def dfwalk1(K):
+    """k_demit's walk in HALF-PIECE mode (a lane owns 32 input bytes: programs whose pieces are too large for a wave's staging area run
+    one walk over twice as many lanes instead of several walks over a part of them): ONE chain of 32 steps from (h, o), the placing and
+    the counted job slots of dfwalk2."""
+    L = []
+    ap = L.append
+    E = DF_WALK_E["A"]
+    pair = lambda k: "v[%s:%s]" % (E[k][0][1:], E[k][1][1:])
+    def cls_issue(t, slot):
+        ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (t >> 2, SD, t & 3))
+        ap("ds_read_u8 %%[c%d], %%[x]" % slot)
+    twof = None
+    ap("s_setprio 3")
+    for d in (0, 1, 2):
+        cls_issue(d, d)
+    ap("s_waitcnt lgkmcnt(2)")
+    ap("v_add_u32 %[a0], %[h], %[c0]")
+    ap("ds_read_b64 %s, %%[a0]" % pair(0))
+    for j in range(32):
+        cur, nxt = j & 1, (j + 1) & 1
+        if j + 3 < 32:
+            cls_issue(j + 3, (j + 3) % 3)
+        # in flight behind the entry read of step j: the previous step's byte store (and its job store, which may not count) and the
+        # class reads issued since
+        ap("s_waitcnt lgkmcnt(%d)" % ((1 if j + 3 < 32 else 0) + (0 if j == 0 else 1)))
+        if j + 1 < 32:
+            ap("v_add_u32_sdwa %%[a%d], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (nxt, E[cur][0], (j + 1) % 3, SD))
+            ap("ds_read_b64 %s, %%[a%d]" % (pair(nxt), nxt))
+        so = j - K
+        hi, a = E[cur][1], "%%[a%d]" % cur
+        if so >= 0:
+            wreg, by = "%%[w%d]" % (so >> 2), so & 3
+        else:
+            wreg, by = "%[wp]", (4 + so) & 3
+        if by in (1, 3) and twof != wreg:
+            ap("v_lshrrev_b32 %%[tw], 8, %s" % wreg)
+            twof = wreg
+        src = "%[tw]" if by in (1, 3) else wreg
+        wr = "ds_write_b8_d16_hi" if by >= 2 else "ds_write_b8"
+        ap("v_cmp_gt_i32_sdwa vcc, 0, sext(%s) src0_sel:DWORD src1_sel:BYTE_2" % hi)
+        ap("v_lshl_or_b32 %s, %%[o], 16, %s" % (a, a))
+        ap("v_lshl_or_b32 %%[x], %s, 31, %%[o]" % hi)
+        ap("v_add_u32_sdwa %%[o], %%[o], %s %s src0_sel:DWORD src1_sel:BYTE_3" % (hi, SD))
+        ap("%s %%[x], %s" % (wr, src))
+        ap("s_and_saveexec_b64 %[sv], vcc")
+        ap("ds_write_b32 %%[p], %s" % a)
+        ap("s_mov_b64 exec, %[sv]")
+        ap("v_add_u32_sdwa %%[p], %%[p], %s %s src0_sel:DWORD src1_sel:BYTE_2" % (E[cur][0], SD))
+    ap("s_setprio 0")
+    return L
+
+
 def main7(out):
     tmp = ["c0", "c1", "c2", "x"]
     clob = ", ".join('"%s"' % r for pr in DF_RUN_E for r in pr)
@@ -590,6 +642,16 @@ def main7(out):
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[lenA] "=&v"(lenA)', '[h] "+v"(h)', '[sum] "+v"(sum)'],
             ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
             '"memory", ' + clob)
+    tmp1 = ["c0", "c1", "c2", "x", "a0", "a1", "tw"]
+    clob1 = ", ".join('"%s"' % r for pr in DF_WALK_E["A"] for r in pr)
+    for K in (1, 2):
+        emit_fn(out, "piece_dfwalk1c_k%d" % K,
+                "const uint32_t (&w)[8], uint32_t wp, uint32_t h, uint32_t& o, uint32_t& p",
+                "uint32_t " + ", ".join(tmp1) + "; unsigned long long sv;",
+                dfwalk1(K),
+                ['[%s] "=&v"(%s)' % (t, t) for t in tmp1] + ['[sv] "=&s"(sv)', '[o] "+v"(o)', '[p] "+v"(p)'],
+                ['[w%d] "v"(w[%d])' % (i, i) for i in range(8)] + ['[wp] "v"(wp)', '[h] "v"(h)'],
+                '"vcc", "scc", "memory", ' + clob1)
     tmp = ["cA0", "cA1", "cA2", "cB0", "cB1", "cB2", "xA", "xB", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
     clob = ", ".join('"%s"' % r for ch in "AB" for pr in DF_WALK_E[ch] for r in pr)
     for K in (1, 2):

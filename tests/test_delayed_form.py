@@ -164,14 +164,16 @@ def test_construction_matches_an_independent_restatement(K):
 
 def test_which_workloads_have_a_delayed_form():
     """apache_log, csv2json and iso_datetime_to_json are decided by two symbols everywhere the start state reaches (apache_log up to the
-    escaped-quote contexts of its quoted fields); thousand_sep and add_commas group digits from the END of a number: no delay decides."""
-    for prog, want in (("apache_log", 1), ("csv2json", 1), ("iso_datetime_to_json", 1), ("flip_ab", 1), ("thousand_sep", 0), ("add_commas", 0)):
+    escaped-quote contexts of its quoted fields).  thousand_sep and add_commas group digits from the END of a number: no delay decides
+    — the table exists (at most a quarter of the start-reachable transitions escape) but every input leaves it in its first pieces
+    (the GPU tests see the fall-back)."""
+    for prog, want in (("apache_log", 1), ("csv2json", 1), ("iso_datetime_to_json", 1), ("flip_ab", 1), ("thousand_sep", 1), ("add_commas", 1)):
         info, _ = host.df_describe(blob_of(prog), with_image=False)
-        assert info.available == want, (prog, info.reason)
+        assert info.available == want, (prog, info.reason, info.escapes_start, info.transitions_start)
     info, _ = host.df_describe(blob_of("csv2json"), with_image=False)
     assert info.escapes == 0 and info.escapes_start == 0           # fully static: no input can escape
     info, _ = host.df_describe(blob_of("apache_log"), with_image=False)
-    assert 0 < info.escapes_start * 16 <= info.transitions_start     # a few contexts (backslash before a quote) stay undecided
+    assert 0 < info.escapes_start * 4 <= info.transitions_start     # a few contexts (backslash before a quote) stay undecided
 
 
 @pytest.mark.parametrize("K", [1, 2])
@@ -285,6 +287,22 @@ def test_engine_runs_the_delayed_form_and_agrees_with_the_general_engine(prog, s
             assert got == want and state == (2 if prog == "apache_log" and K == 1 and n > 100 else 1), (prog, n, K, state)
         got, state = _run(blob, data, KX_DF=0)
         assert got == want and state == 0
+
+
+@pytest.mark.gpu
+def test_program_that_always_escapes_settles_on_the_general_engine():
+    """thousand_sep: where the commas go is decided by the END of the number.  The first run leaves the delayed form in its first
+    pieces and is redone by the general engine; the stage stays there."""
+    blob = blob_of("thousand_sep")
+    data = workloads.generate("numbers", 1 << 20, 6)
+    want = oracle.run(blob, data)
+    p = Program(blob)
+    try:
+        assert p.stage_delayed_form(0) == 1
+        assert p.run_host(data) == want and p.stage_delayed_form(0) == 2
+        assert p.run_host(data) == want and p.stage_delayed_form(0) == 2
+    finally:
+        p.close()
 
 
 @pytest.mark.gpu

@@ -90,9 +90,10 @@ int kx_stage_has_actions(const kx_program* prog, uint32_t stage);
  * with fixed delay K — a forward pass for the lengths and one fused walk that places the bytes; no backward pass.  A context
  * that K symbols do not decide is noticed at run time and the shard is redone by the general engine (and the stage's later
  * shards go there directly): results never depend on which engine ran.  Environment: KX_DF=0 switches the delayed form off,
- * KX_DF=2 takes it whatever the share of undecided contexts, KX_DF_K=1|2 sets the delay (default 2).
+ * KX_DF=2 takes it whatever the share of undecided contexts, KX_DF_K=1|2 pins the delay (default: 1 where one symbol decides every
+ * transition the start state reaches, else 2).
  * kx_df_describe needs no device: it builds the form from the blob (as kx_load does) and reports it; `image`, if not NULL,
- * receives up to image_cap bytes of the table image (class*8 u8[256] | rows of C x {lo = handle of the next state's row,
+ * receives up to image_cap bytes of the table image (class*8 u8[256] — the class index where a stage has more than 31 byte classes — | rows of C x {lo = handle of the next state's row,
  * hi = what the step writes: bit 0 no byte copied, bits 10-22 pool offset/16 of the constant, bit 23 a constant follows,
  * bits 24-30 bytes appended} | pool).  kx_df_pending: what slot j (0 = oldest) of product state `state` still owes, per leaf
  * of its SST state: copy | path-constant id << 1 (n_out = 1: the same for every leaf) — the host evaluates these at the end

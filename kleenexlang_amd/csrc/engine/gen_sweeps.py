@@ -464,7 +464,7 @@ DF_RUN_E = (("v76", "v77"), ("v78", "v79"))   # (below 80: k_dforward keeps 6 wa
 DF_WALK_E = {"A": (("v116", "v117"), ("v118", "v119")), "B": (("v120", "v121"), ("v122", "v123"))}
 
 
-def dfrun1():
+def dfrun1(wide=False):
     """k_dforward's piece: one chain of 64 product transitions from handle h; sum = bytes the steps write (entry hi, byte 3).
     mid / lenA = state and sum after 32 steps.  Per byte: 1 SDWA byte extract, 1 ds_read_u8 (class*8), 1 SDWA add on the chain,
     1 ds_read_b64, 1 SDWA add for the length."""
@@ -478,6 +478,8 @@ def dfrun1():
     for tt in (0, 1, 2):
         cls_issue(tt)
     ap("s_waitcnt lgkmcnt(2)")
+    if wide:   # (more than 31 byte classes: the class table holds the class index, a row's entries are 8 bytes apart)
+        ap("v_lshlrev_b32 %[c0], 3, %[c0]")
     ap("v_add_u32 %[x], %[h], %[c0]")
     ap("ds_read_b64 %s, %%[x]" % pair(0))
     for j in range(64):
@@ -486,6 +488,8 @@ def dfrun1():
             cls_issue(j + 3)
         ap("s_waitcnt lgkmcnt(%d)" % (1 if j + 3 < 64 else 0))
         if j + 1 < 64:
+            if wide:
+                ap("v_lshlrev_b32 %%[c%d], 3, %%[c%d]" % ((j + 1) % 3, (j + 1) % 3))
             ap("v_add_u32_sdwa %%[x], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (E[cur][0], (j + 1) % 3, SD))
             ap("ds_read_b64 %s, %%[x]" % pair(nxt))
         # (lo's upper half = bytes appended << 8 | 4 x "a constant follows": the sum's low byte counts the constants, its bits 8.. the bytes)
@@ -499,7 +503,7 @@ def dfrun1():
     return L
 
 
-def dfwalk2(K, counted=True):
+def dfwalk2(K, counted=True, wide=False):
     """k_demit's fused walk for delay K: chain A = steps 0..31 from (hA, oA), chain B = steps 32..63 from (hB, oB); step s reads the
     class of input byte s, takes the product transition, and places what the entry says: input byte s-K (if the entry copies) at
     the cursor, a job for the constant (if one follows), cursor += bytes appended.  Job noting is k_emit's branch-free form
@@ -519,6 +523,8 @@ def dfwalk2(K, counted=True):
             cls_issue(ch, base[ch] + d, d)
     ap("s_waitcnt lgkmcnt(2)")
     for ch in "AB":
+        if wide:
+            ap("v_lshlrev_b32 %%[c%s0], 3, %%[c%s0]" % (ch, ch))
         ap("v_add_u32 %%[a%s0], %%[h%s], %%[c%s0]" % (ch, ch, ch))
         ap("ds_read_b64 %s, %%[a%s0]" % (pair(ch, 0), ch))
     for j in range(32):
@@ -532,6 +538,8 @@ def dfwalk2(K, counted=True):
         ap("s_waitcnt lgkmcnt(%d)" % (2 if j == 0 else (4 if counted else 6) if j + 2 < 32 else (2 if counted else 4)))
         if j + 1 < 32:
             for ch in "AB":
+                if wide:
+                    ap("v_lshlrev_b32 %%[c%s%d], 3, %%[c%s%d]" % (ch, (j + 1) % 3, ch, (j + 1) % 3))
                 ap("v_add_u32_sdwa %%[a%s%d], %s, %%[c%s%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (ch, nxt, E[ch][cur][0], ch, (j + 1) % 3, SD))
                 ap("ds_read_b64 %s, %%[a%s%d]" % (pair(ch, nxt), ch, nxt))
         for ch in "AB":
@@ -580,7 +588,7 @@ def dfwalk2(K, counted=True):
     return L
 
 
-def dfwalk1(K):
+def dfwalk1(K, wide=False):
     """k_demit's walk in HALF-PIECE mode (a lane owns 32 input bytes: programs whose pieces are too large for a wave's staging area run
     one walk over twice as many lanes instead of several walks over a part of them): ONE chain of 32 steps from (h, o), the placing and
     the counted job slots of dfwalk2."""
@@ -596,6 +604,8 @@ def dfwalk1(K):
     for d in (0, 1, 2):
         cls_issue(d, d)
     ap("s_waitcnt lgkmcnt(2)")
+    if wide:
+        ap("v_lshlrev_b32 %[c0], 3, %[c0]")
     ap("v_add_u32 %[a0], %[h], %[c0]")
     ap("ds_read_b64 %s, %%[a0]" % pair(0))
     for j in range(32):
@@ -606,6 +616,8 @@ def dfwalk1(K):
         # class reads issued since
         ap("s_waitcnt lgkmcnt(%d)" % ((1 if j + 3 < 32 else 0) + (0 if j == 0 else 1)))
         if j + 1 < 32:
+            if wide:
+                ap("v_lshlrev_b32 %%[c%d], 3, %%[c%d]" % ((j + 1) % 3, (j + 1) % 3))
             ap("v_add_u32_sdwa %%[a%d], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (nxt, E[cur][0], (j + 1) % 3, SD))
             ap("ds_read_b64 %s, %%[a%d]" % (pair(nxt), nxt))
         so = j - K
@@ -635,6 +647,13 @@ def dfwalk1(K):
 def main7(out):
     tmp = ["c0", "c1", "c2", "x"]
     clob = ", ".join('"%s"' % r for pr in DF_RUN_E for r in pr)
+    emit_fn(out, "piece_dfrun1w",
+            "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid, uint32_t& lenA, uint32_t& sum",
+            "uint32_t " + ", ".join(tmp) + ";",
+            dfrun1(True),
+            ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[lenA] "=&v"(lenA)', '[h] "+v"(h)', '[sum] "+v"(sum)'],
+            ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
+            '"memory", ' + clob)
     emit_fn(out, "piece_dfrun1",
             "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid, uint32_t& lenA, uint32_t& sum",
             "uint32_t " + ", ".join(tmp) + ";",
@@ -644,21 +663,21 @@ def main7(out):
             '"memory", ' + clob)
     tmp1 = ["c0", "c1", "c2", "x", "a0", "a1", "tw"]
     clob1 = ", ".join('"%s"' % r for pr in DF_WALK_E["A"] for r in pr)
-    for K in (1, 2):
-        emit_fn(out, "piece_dfwalk1c_k%d" % K,
+    for K, wd in ((1, False), (2, False), (1, True), (2, True)):
+        emit_fn(out, "piece_dfwalk1c%s_k%d" % ("w" if wd else "", K),
                 "const uint32_t (&w)[8], uint32_t wp, uint32_t h, uint32_t& o, uint32_t& p",
                 "uint32_t " + ", ".join(tmp1) + "; unsigned long long sv;",
-                dfwalk1(K),
+                dfwalk1(K, wd),
                 ['[%s] "=&v"(%s)' % (t, t) for t in tmp1] + ['[sv] "=&s"(sv)', '[o] "+v"(o)', '[p] "+v"(p)'],
                 ['[w%d] "v"(w[%d])' % (i, i) for i in range(8)] + ['[wp] "v"(wp)', '[h] "v"(h)'],
                 '"vcc", "scc", "memory", ' + clob1)
     tmp = ["cA0", "cA1", "cA2", "cB0", "cB1", "cB2", "xA", "xB", "aA0", "aA1", "aB0", "aB1", "twA", "twB"]
     clob = ", ".join('"%s"' % r for ch in "AB" for pr in DF_WALK_E[ch] for r in pr)
-    for K in (1, 2):
-        emit_fn(out, "piece_dfwalk2c_k%d" % K,
+    for K, wd in ((1, False), (2, False), (1, True), (2, True)):
+        emit_fn(out, "piece_dfwalk2c%s_k%d" % ("w" if wd else "", K),
                 "const uint32_t (&w)[16], uint32_t wp, uint32_t hA, uint32_t& oA, uint32_t hB, uint32_t& oB, uint32_t& pA, uint32_t& pB",
                 "uint32_t " + ", ".join(tmp) + "; unsigned long long sv;",
-                dfwalk2(K, counted=True),
+                dfwalk2(K, counted=True, wide=wd),
                 ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[sv] "=&s"(sv)', '[oA] "+v"(oA)', '[oB] "+v"(oB)', '[pA] "+v"(pA)', '[pB] "+v"(pB)'],
                 ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)] + ['[wp] "v"(wp)', '[hA] "v"(hA)', '[hB] "v"(hB)'],
                 '"vcc", "scc", "memory", ' + clob)

@@ -44,6 +44,7 @@ struct DfState { uint32_t q; std::vector<Slot> pend; };
 
 struct DfBuild {
   uint32_t K = 0, C = 0, nP = 0;
+  bool wide = false;                       // more than 31 byte classes: the class table holds class indices (else class * 8)
   std::vector<uint32_t> img;               // LDS image: [class*8 u8[256] | rows (nP + 2) x C x {lo, hi} | pool]
   // pool: every path constant FOUR times — copy s = the constant from its byte s on, zero-padded to plen = (length + 15) & ~15
   // bytes, the copies one behind the other from a 16-byte boundary — so that k_demit can store the part of a constant behind the
@@ -74,7 +75,8 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   const uint32_t C = in.C, Lm = in.Lm;
   if (K == 0 || K > DF_MAX_K) return "delay out of range";
   if (in.has_tbl) return "symbol tables";
-  if (C > 31) return "more than 31 byte classes";
+  if (C > 255) return "more than 255 byte classes";
+  out.wide = C > 31;   // class * 8 no longer fits the class table's byte: it holds the class index and the kernels shift
   if ((in.apool_bytes >> 4) >= (1u << 13)) return "constant pool too large";
   auto pcOf = [&](uint32_t e) { return e >> 9; };
   // canonical constant ids (by content), lengths
@@ -225,7 +227,7 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   out.off_pool = (uint32_t)off_pool;
   out.img.assign((off_pool + pool.size() + 3) / 4, 0u);
   uint8_t* ib = (uint8_t*)out.img.data();
-  for (int b = 0; b < 256; ++b) ib[b] = (uint8_t)(in.cls[b] * 8);
+  for (int b = 0; b < 256; ++b) ib[b] = (uint8_t)(out.wide ? in.cls[b] : in.cls[b] * 8);
   auto entryHi = [&](Kind k) -> uint32_t {
     const uint32_t copy = k & 1u, pc = k >> 1;
     const uint32_t cl = pc < in.npc ? clen[pc] : 0u;

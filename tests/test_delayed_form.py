@@ -55,8 +55,9 @@ def simulate(blob, info, img, data, K):
     C, dead, esc = info.nclasses, info.dead_handle, info.escape_handle
     h = info.start_handle
     out = bytearray()
+    csh = 3 if C > 31 else 0     # (more than 31 byte classes: the class table holds class indices)
     for s, b in enumerate(data):
-        a = h + img[b]
+        a = h + (img[b] << csh)
         lo, hi = struct.unpack_from("<II", img, a)
         h = lo & 0xFFFF
         if h == dead:
@@ -254,6 +255,32 @@ def test_simulated_table_against_the_oracle_on_random_programs():
     assert checked > 800 and escaped > 0, (checked, escaped)
 
 
+def many_classes_program(width):
+    """40 letters, each with its own replacement (a rot13-like table written out as alternatives: every letter is a byte class of its
+    own — more than the 31 whose class * 8 fits the class table's byte), digits copied; `width` = bytes a letter becomes."""
+    letters = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMN"
+    alts = " | ".join('~/%s/ "%s"' % (c, (c.swapcase() + c) * (width // 2)) for c in letters)
+    return "main := (%s | /[0-9 ]/)*\n" % alts, letters
+
+
+def test_more_than_31_byte_classes():
+    r = random.Random(11)
+    for width in (2, 8):
+        src, letters = many_classes_program(width)
+        blob = blob_of(src)
+        assert kxp.parse(blob)[0].nclasses > 31
+        # (the engine's own choice of delay: one symbol decides everything here, and a second would square the 42 kinds of output
+        #  that wait in the state — beyond the image budget)
+        info, img = host.df_describe(blob)
+        assert info.available == 1 and info.escapes == 0 and info.delay == 1, (info.reason, info.delay)
+        assert describe(blob, 2)[0].available == 0
+        for n in (0, 1, 5, 300):
+            data = bytes(r.choice((letters + "0123456789 ").encode()) for _ in range(n))
+            assert simulate(blob, info, img, data, 1) == expect(blob, data), (width, data)
+        bad = b"abc" + b"?" + b"def"
+        assert simulate(blob, info, img, bad, 1) == expect(blob, bad) == ("fail", 3)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 def _run(blob, data, **env):
     old = {k: os.environ.get(k) for k in env}
@@ -287,6 +314,26 @@ def test_engine_runs_the_delayed_form_and_agrees_with_the_general_engine(prog, s
             assert got == want and state == (2 if prog == "apache_log" and K == 1 and n > 100 else 1), (prog, n, K, state)
         got, state = _run(blob, data, KX_DF=0)
         assert got == want and state == 0
+
+
+@pytest.mark.gpu
+def test_more_than_31_byte_classes_on_the_engine():
+    """The class table of such a stage holds class indices and the sequences shift (`piece_dfrun1w`, `piece_dfwalk2cw_*`, `piece_dfwalk1cw_*`);
+    width 8 makes the output four times the input: a lane takes half a piece."""
+    r = random.Random(12)
+    for width in (2, 8):
+        src, letters = many_classes_program(width)
+        blob = blob_of(src)
+        for n in (100, 70000, 3 << 20):
+            data = bytes(r.choice((letters + "0123456789 ").encode()) for _ in range(min(n, 70000))) * max(1, n // 70000)
+            want = expect(blob, data)
+            got, state = _run(blob, data)
+            assert got == want and state == 1, (width, n)
+            got, state = _run(blob, data, KX_DF=0)
+            assert got == want and state == 0
+        bad = data[:100000] + b"?" + data[100001:]
+        got, _ = _run(blob, bad)
+        assert got == expect(blob, bad)
 
 
 @pytest.mark.gpu

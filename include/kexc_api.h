@@ -115,9 +115,13 @@ typedef struct kexc_pipeline { int is_oracle_action; uint32_t nprograms; const k
  *   Maybe FilePath source    -> srcout_path      (the KXP blob is this back end's "source")
  *   Bool word alignment      -> word_alignment   (accepted, unused: the device output is a byte stream)
  * Returns the exit code (0 = ExitSuccess); on failure the message is in kexc_last_error(). */
-int kexc_emit_pipeline(int buffer_unit_bits, int cc_opt_level, void (*info)(const char* line, void* ctx), void* info_ctx,
-                       const kexc_pipeline* pipeline, const char* env_info, const char* cc, const char* out_path,
-                       const char* srcout_path, int word_alignment);
+/* The exported symbol carries the version of the records it reads: kexc_pipeline grew a field (program_size) in round 4, and a
+ * caller built against the older, shorter struct must not reach code that reads the longer one — it now fails to link / to look
+ * the symbol up instead.  Source keeps the reference's name through the macro. */
+#define kexc_emit_pipeline kexc_emit_pipeline_v2
+int kexc_emit_pipeline_v2(int buffer_unit_bits, int cc_opt_level, void (*info)(const char* line, void* ctx), void* info_ctx,
+                          const kexc_pipeline* pipeline, const char* env_info, const char* cc, const char* out_path,
+                          const char* srcout_path, int word_alignment);
 
 /* Compile Kleenex source text (direct mode, --la=false semantics) to a KXP blob.
  * opt_level = the reference's `--opt` (0..3, SymbolicSST.optimize).

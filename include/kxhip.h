@@ -161,7 +161,7 @@ void kx_shard_end(kx_shard* s);
 /* ---- the multi-GPU driver: the protocol above, run by the library itself ---------------------------------------
  * One rank per GPU (a process, or a thread of one process); rank r holds shard r of the input on its own current device.
  * kx_run_sharded runs every pipeline stage over the rank's shard and takes part in the boundary hand-off — four
- * all-gathers of fixed-size records per stage (40, 40, 272 and 8 bytes per rank), nothing else crosses ranks — through
+ * all-gathers of fixed-size records per stage (40, 40, 272 and 16 bytes per rank; one more of 16 bytes behind the last stage's emit), nothing else crosses ranks — through
  * the all-gather it is given:
  *   kx_comm_*   RCCL: `ncclAllGather` on the communicator's own device buffers and stream (xGMI between the GPUs of a node;
  *               librccl is dlopen'ed).  Rank 0 makes the 128-byte id (kx_comm_unique_id) and the launcher hands it to every

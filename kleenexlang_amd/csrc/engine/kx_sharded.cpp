@@ -7,7 +7,7 @@
 // (or that this depends on the state it starts in) and, backward, the leaf it starts in per leaf it ends in.
 //
 // Per pipeline stage a rank runs the kx_shard_* phases on its own shard and takes part in four all-gathers of fixed-size
-// records (40, 40, 272 and 8 bytes per rank): states forward (before and after the shard heads are fixed), leaves backward,
+// records (40, 40, 272 and 16 bytes per rank): states forward (before and after the shard heads are fixed), leaves backward,
 // output sizes.  The all-gather is a callback:
 //   kx_comm_*   RCCL (`ncclAllGather` on small device buffers of its own communicator; librccl is dlopen'ed so that the
 //               engine library has no link-time dependency on it) — one process per GPU, xGMI between them;

@@ -388,10 +388,10 @@ def emit_pipeline(programs, env_info=None, out=None, srcout=None, buffer_unit_bi
     pl = KexcPipeline(1 if oracle_action else 0, len(programs), structs, ctypes.sizeof(KexcIlProgram) if program_size is None else program_size)
     CB = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_void_p)
     cb = CB((lambda line, ctx: info(line.decode())) if info else (lambda line, ctx: None))
-    lib.kexc_emit_pipeline.argtypes = [ctypes.c_int, ctypes.c_int, CB, ctypes.c_void_p, ctypes.POINTER(KexcPipeline), ctypes.c_char_p,
+    lib.kexc_emit_pipeline_v2.argtypes = [ctypes.c_int, ctypes.c_int, CB, ctypes.c_void_p, ctypes.POINTER(KexcPipeline), ctypes.c_char_p,
                                        ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
     enc = lambda x: None if x is None else str(x).encode()
-    rc = lib.kexc_emit_pipeline(buffer_unit_bits, copt, cb, None, ctypes.byref(pl), enc(env_info), enc(cc), enc(out), enc(srcout), 1 if word_alignment else 0)
+    rc = lib.kexc_emit_pipeline_v2(buffer_unit_bits, copt, cb, None, ctypes.byref(pl), enc(env_info), enc(cc), enc(out), enc(srcout), 1 if word_alignment else 0)
     if rc:
         raise CompileError(lib.kexc_last_error().decode("utf-8", "replace"))
     return rc

@@ -26,7 +26,7 @@ def test_kxhip_exports_every_declared_symbol():
 def test_kexc_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(build.OUT, "libkexc.so"))
     names = _declared("kexc_api.h")
-    assert set(names) == {"kexc_compile", "kexc_emit_c", "kexc_emit_pipeline", "kexc_dump_fst", "kexc_compile_regex", "kexc_dump_regex_fst",
+    assert set(names) == {"kexc_compile", "kexc_emit_c", "kexc_emit_pipeline_v2", "kexc_dump_fst", "kexc_compile_regex", "kexc_dump_regex_fst",
                           "kexc_compile_flags", "kexc_dump_words",
                           "kexc_last_error", "kexc_free"}
     for n in names:

@@ -88,8 +88,8 @@ int kx_stage_has_actions(const kx_program* prog, uint32_t stage);
 /* ---- the delayed form of a stage (round 5; kleenexlang_amd/csrc/engine/kx_delayed.h) -----------------------------------
  * Where every step's output is decided by at most K further input symbols the engine runs the stage as a forward transducer
  * with fixed delay K — a forward pass for the lengths and one fused walk that places the bytes; no backward pass.  A context
- * that K symbols do not decide is noticed at run time and the shard is redone by the general engine (and the stage's later
- * shards go there directly): results never depend on which engine ran.  Environment: KX_DF=0 switches the delayed form off,
+ * that K symbols do not decide is noticed at run time and the shard is redone by the general engine (and the stage backs off
+ * from the form for a while): results never depend on which engine ran.  Environment: KX_DF=0 switches the delayed form off,
  * KX_DF=2 takes it whatever the share of undecided contexts, KX_DF_K=1|2 pins the delay (default: 1 where one symbol decides every
  * transition the start state reaches, else 2).
  * kx_df_describe needs no device: it builds the form from the blob (as kx_load does) and reports it; `image`, if not NULL,
@@ -111,7 +111,8 @@ typedef struct kx_df_info {
 int kx_df_describe(const void* blob, size_t blob_len, uint32_t stage, kx_df_info* info, void* image, size_t image_cap);
 int kx_df_pending(const void* blob, size_t blob_len, uint32_t stage, uint32_t state, uint32_t slot, uint32_t* sst_state,
                   uint32_t* kinds, uint32_t* n_out);
-/* of a loaded program: 0 the stage has no delayed form, 1 it runs on it, 2 it had one and a shard gave it up (escape) */
+/* of a loaded program: 0 the stage has no delayed form, 1 its next shard runs on it, 2 a shard gave it up (escape) and the stage is backing
+ * off: after the k-th fall-back in a row the next 2^k - 1 shards (at most 63) go straight to the general engine, then the form is tried again */
 int kx_stage_delayed_form(const kx_program* prog, uint32_t stage);
 
 /* Whole program (all pipeline stages) over one device-resident input.

@@ -337,17 +337,22 @@ def test_more_than_31_byte_classes_on_the_engine():
 
 
 @pytest.mark.gpu
-def test_program_that_always_escapes_settles_on_the_general_engine():
-    """thousand_sep: where the commas go is decided by the END of the number.  The first run leaves the delayed form in its first
-    pieces and is redone by the general engine; the stage stays there."""
+def test_program_that_always_escapes_backs_off_from_the_delayed_form():
+    """thousand_sep: where the commas go is decided by the END of the number.  Every run that tries the delayed form leaves it in its
+    first pieces and is redone by the general engine; after the k-th such run in a row the stage sends its next 2^k - 1 runs to the
+    general engine directly before it tries again (kx_stage_delayed_form: 2 while it is backing off)."""
     blob = blob_of("thousand_sep")
     data = workloads.generate("numbers", 1 << 20, 6)
     want = oracle.run(blob, data)
     p = Program(blob)
     try:
         assert p.stage_delayed_form(0) == 1
-        assert p.run_host(data) == want and p.stage_delayed_form(0) == 2
-        assert p.run_host(data) == want and p.stage_delayed_form(0) == 2
+        states = []
+        for _ in range(7):
+            assert p.run_host(data) == want
+            states.append(p.stage_delayed_form(0))
+        # run 1 tries and escapes (1 run to skip), run 2 skips, run 3 tries and escapes (3 to skip), runs 4-6 skip, run 7 tries (7 to skip)
+        assert states == [2, 1, 2, 2, 2, 1, 2], states
     finally:
         p.close()
 
@@ -371,8 +376,9 @@ def test_escape_in_mid_run_falls_back_to_the_general_engine():
         assert p.stage_delayed_form(0) == 1
         assert p.run_host(base) == oracle.run(blob, base) and p.stage_delayed_form(0) == 1
         assert p.run_host(data) == want
-        assert p.stage_delayed_form(0) == 2
-        assert p.run_host(base) == oracle.run(blob, base)
+        assert p.stage_delayed_form(0) == 2                                            # backing off: the next run goes to the general engine
+        assert p.run_host(base) == oracle.run(blob, base) and p.stage_delayed_form(0) == 1
+        assert p.run_host(base) == oracle.run(blob, base) and p.stage_delayed_form(0) == 1   # on the form again
     finally:
         p.close()
     bad = base[:700000] + b"\x00" + base[700001:]

@@ -460,18 +460,17 @@ def main2(out):
 # ------------------------------------------------------------------------------------------------ delayed form (round 5)
 # Entries of the delayed form's table are 8 bytes {lo, hi} (kx_dfkernels.inc), read with one ds_read_b64 into a register PAIR;
 # inline-asm operands cannot name the halves of a pair, so the sequences below use fixed registers for them (listed as clobbers).
-DF_RUN_E = (("v76", "v77"), ("v78", "v79"))   # (below 80: k_dforward keeps 6 waves per SIMD)
 DF_WALK_E = {"A": (("v116", "v117"), ("v118", "v119")), "B": (("v120", "v121"), ("v122", "v123"))}
 
 
 def dfrun1(wide=False):
     """k_dforward's piece: one chain of 64 product transitions from handle h; sum = bytes the steps write (entry hi, byte 3).
     mid / lenA = state and sum after 32 steps.  Per byte: 1 SDWA byte extract, 1 ds_read_u8 (class*8), 1 SDWA add on the chain,
-    1 ds_read_b64, 1 SDWA add for the length."""
+    1 ds_read_b32 (the entry's LOW word: next handle, bytes appended, "a constant follows" — the high word is the walks'; reading
+    it too, as the first version did, doubled the data this kernel pulls out of LDS), 1 SDWA add for the length."""
     L = []
     ap = L.append
-    E = DF_RUN_E
-    pair = lambda k: "%s[%s:%s]" % ("v", E[k][0][1:], E[k][1][1:])
+    E = (("%[e0]",), ("%[e1]",))
     def cls_issue(tt):
         ap("v_lshlrev_b32_sdwa %%[x], 0, %%[w%d] %s src0_sel:DWORD src1_sel:BYTE_%d" % (tt >> 2, SD, tt & 3))
         ap("ds_read_u8 %%[c%d], %%[x]" % (tt % 3))
@@ -481,7 +480,7 @@ def dfrun1(wide=False):
     if wide:   # (more than 31 byte classes: the class table holds the class index, a row's entries are 8 bytes apart)
         ap("v_lshlrev_b32 %[c0], 3, %[c0]")
     ap("v_add_u32 %[x], %[h], %[c0]")
-    ap("ds_read_b64 %s, %%[x]" % pair(0))
+    ap("ds_read_b32 %s, %%[x]" % E[0][0])
     for j in range(64):
         cur, nxt = j & 1, (j + 1) & 1
         if j + 3 < 64:
@@ -491,7 +490,7 @@ def dfrun1(wide=False):
             if wide:
                 ap("v_lshlrev_b32 %%[c%d], 3, %%[c%d]" % ((j + 1) % 3, (j + 1) % 3))
             ap("v_add_u32_sdwa %%[x], %s, %%[c%d] %s src0_sel:WORD_0 src1_sel:DWORD" % (E[cur][0], (j + 1) % 3, SD))
-            ap("ds_read_b64 %s, %%[x]" % pair(nxt))
+            ap("ds_read_b32 %s, %%[x]" % E[nxt][0])
         # (lo's upper half = bytes appended << 8 | 4 x "a constant follows": the sum's low byte counts the constants, its bits 8.. the bytes)
         ap("v_add_u32_sdwa %%[sum], %%[sum], %s %s src0_sel:DWORD src1_sel:WORD_1" % (E[cur][0], SD))
         if j == 31:
@@ -645,22 +644,21 @@ def dfwalk1(K, wide=False):
 
 
 def main7(out):
-    tmp = ["c0", "c1", "c2", "x"]
-    clob = ", ".join('"%s"' % r for pr in DF_RUN_E for r in pr)
+    tmp = ["c0", "c1", "c2", "x", "e0", "e1"]
     emit_fn(out, "piece_dfrun1w",
             "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid, uint32_t& lenA, uint32_t& sum",
             "uint32_t " + ", ".join(tmp) + ";",
             dfrun1(True),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[lenA] "=&v"(lenA)', '[h] "+v"(h)', '[sum] "+v"(sum)'],
             ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
-            '"memory", ' + clob)
+            '"memory"')
     emit_fn(out, "piece_dfrun1",
             "const uint32_t (&w)[16], uint32_t& h, uint32_t& mid, uint32_t& lenA, uint32_t& sum",
             "uint32_t " + ", ".join(tmp) + ";",
             dfrun1(),
             ['[%s] "=&v"(%s)' % (t, t) for t in tmp] + ['[mid] "=&v"(mid)', '[lenA] "=&v"(lenA)', '[h] "+v"(h)', '[sum] "+v"(sum)'],
             ['[w%d] "v"(w[%d])' % (i, i) for i in range(16)],
-            '"memory", ' + clob)
+            '"memory"')
     tmp1 = ["c0", "c1", "c2", "x", "a0", "a1", "tw"]
     clob1 = ", ".join('"%s"' % r for pr in DF_WALK_E["A"] for r in pr)
     for K, wd in ((1, False), (2, False), (1, True), (2, True)):

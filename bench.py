@@ -25,12 +25,49 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ≈6.3 TB/s achievable)
-# with today's instruction counts per 4 KiB (k_forward + k_backlen + k_emit, SQ counters of profiles/r04z_*) and the
-# measured ≈ 3.7 SIMD-cycles per wave-instruction the three kernels cannot run faster than this fraction of 8 TB/s.
-ISSUE_BOUND_FRAC = {"apache_log": 0.101}
-# the delayed form (round 5): k_dforward + k_demit issue 390 + 946 = 1 336 vector instructions per 4 KiB (profiles/r05z_sq_counters.json): at
-# one VALU issue per SIMD every 4 cycles that is 1 336 CU-cycles per 4 KiB = 5.7 ms per 10 GiB = 1.89 TB/s of input
-ISSUE_BOUND_FRAC_DELAYED = {"apache_log": 0.236}
+HBM_ACHIEVABLE_GBPS = 6300.0
+
+
+def counter_ceilings(program, kernels, n_cus=256):
+    """Ceilings that follow from the engine's own instruction and LDS-pipe counts — read from an SQ-counter file taken with THIS engine
+    build (profiles/*sq_counters*.json stamped with build.engine_sha() by profiles/collect_sq_df.sh); None when there is no such file
+    (round 5 printed literals here).  Per kernel of `kernels`, per input byte of the counter run:
+      issue:  (SQ_INSTS_VALU + SQ_INSTS_LDS) wave-instructions x 4 cycles on one of 4 x n_cus SIMDs (a SIMD issues one vector instruction
+              every 4 cycles whatever the wave),
+      lds:    SQ_LDS_IDX_ACTIVE cycles of one of n_cus LDS pipes,
+    both at the shader clock of the counter run (GRBM_GUI_ACTIVE / kernel time is not in the file: 2.4 GHz nominal is used)."""
+    import glob
+    from kleenexlang_amd import build as kbuild
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json")), reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:   # noqa: BLE001
+            continue
+        if j.get("engine_sha") != kbuild.engine_sha() or j.get("program", "apache_log") != program or not j.get("input_bytes"):
+            continue
+        ks = [k for k in kernels if k in j["kernels"]]
+        if not ks:
+            continue
+        nb, clk = float(j["input_bytes"]), 2.4e9
+        issue_s = sum((j["kernels"][k]["SQ_INSTS_VALU"] + j["kernels"][k]["SQ_INSTS_LDS"]) * 4.0 / (4 * n_cus) for k in ks) / clk
+        lds_s = sum(j["kernels"][k]["SQ_LDS_IDX_ACTIVE"] / n_cus for k in ks) / clk
+        return {"issue_bound_frac": round(nb / issue_s / 1e9 / HBM_PEAK_GBPS, 4), "lds_pipe_bound_frac": round(nb / lds_s / 1e9 / HBM_PEAK_GBPS, 4),
+                "kernels": ks, "source": os.path.basename(f)}
+    return None
+
+
+def gpu_clocks():
+    """sclk / mclk / power of device 0 as rocm-smi reports them (explains the boxes that run every kernel 1.3-1.5x slower); None if the
+    tool is missing or silent."""
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--json"], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=20)
+        j = json.loads(r.stdout.decode() or "{}")
+        card = next(iter(j.values())) if j else {}
+        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "power", "performance"))}
+        return keep or None
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def cpu_baseline(program, base, sample_bytes):
@@ -197,15 +234,22 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
+    clocks_before = gpu_clocks() if rank == 0 else None
     kern = {}
+    step_ms = []          # wall time of every step (a step blocks until its output is complete: no extra synchronisation)
     totals["boundary_ms"] = 0.0
     t0 = time.perf_counter()
+    tprev = t0
     for _ in range(a.steps):
         olen = step()
+        tnow = time.perf_counter()
+        step_ms.append((tnow - tprev) * 1e3)
+        tprev = tnow
         for kname, ms in prog.last_stats.as_dict()["kernel_ms"].items():
             kern[kname] = kern.get(kname, 0.0) + ms
     fence()
     dt = time.perf_counter() - t0
+    clocks_after = gpu_clocks() if rank == 0 else None
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,14 +305,16 @@ def main():
         line = {
             "metric": "input GB/s + % HBM-read roofline, apache_log.kex over 10 GiB synthetic log",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "ms_per_step_median": round(sorted(step_ms)[len(step_ms) // 2], 3),
+            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s.kex, %.2f GiB synthetic %s per GPU (seeded 32 MiB chunk replicated, "
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
                        "input_bytes_per_gpu": n_local, "output_bytes_rank0": olen, "output_bytes_total": total_out,
                        "segment_bytes": a.segment or "auto (one round of lanes: input / (CUs x 1024), 4-64 KiB)",
                        "engine": ("delayed form (forward transducer with fixed delay, no backward pass; DESIGN.md §2e)" if delayed else
-                                  "general (forward, backward, sweep)" + (" after the delayed form met an undecided context" if df_state == 2 else "")),
+                                  "general (forward, backward, sweep)" + (" after the delayed form met an undecided context" if df_state == 2 else
+                                                                           " (the delayed form was given up: the input leaves it in nearly every segment)" if df_state == 3 else "")),
                        "parallelism": "shard%d" % world, "boundary_backend": (a.backend if use_dist else None),
                        "boundary_driver": (None if not use_dist else "python (sharded.py over torch.distributed)" if a.py_driver else "kx_run_sharded (C, own RCCL communicator)"),
                        "boundary_ms_per_step_rank0": (round(totals["boundary_ms"] / a.steps, 4) if comm is not None else None),
@@ -280,18 +326,20 @@ def main():
             # byte over a bus that sustains ≈ 6.3 TB/s in mixed traffic; this three-pass design moves 3 + r + 3/16 B.  Both are
             # bounds of the WHOLE PATH (compare `whole_path.frac_of_hbm_peak`), stated as fractions of the 8 TB/s read roofline.
             "ceilings": {"out_over_in": round(ratio, 4),
-                         "single_pass_hbm_bound_frac": round(6300.0 / (1.0 + ratio) / HBM_PEAK_GBPS, 4),
-                         "this_design_hbm_bound_frac": round(6300.0 / ((2.5 if delayed else 3.0 + 3.0 / 16.0) + ratio) / HBM_PEAK_GBPS, 4),
-                         "this_design_issue_bound_frac": (ISSUE_BOUND_FRAC_DELAYED if delayed else ISSUE_BOUND_FRAC).get(a.program),
+                         "single_pass_hbm_bound_frac": round(HBM_ACHIEVABLE_GBPS / (1.0 + ratio) / HBM_PEAK_GBPS, 4),
+                         "this_design_hbm_bound_frac": round(HBM_ACHIEVABLE_GBPS / ((2.5 if delayed else 3.0 + 3.0 / 16.0) + ratio) / HBM_PEAK_GBPS, 4),
+                         "from_counters": counter_ceilings(a.program, ["k_dforward", "k_demit"] if delayed else ["k_forward", "k_backlen", "k_emit"]),
                          "note": "fractions of 8 TB/s; north_star's 40 % is above the single-pass HBM bound for this output ratio; this design reads the "
-                                 "input twice (delayed form; three times on the general engine) plus its piece records; the issue bound is vector "
-                                 "instructions per 4 KiB x 4 SIMD-cycles each (one VALU issue per SIMD and 4 cycles, DESIGN.md §4) at today's counts"},
+                                 "input twice (delayed form; three times on the general engine) plus its piece records; from_counters: what the engine's "
+                                 "own vector-instruction count and LDS-pipe cycles allow (SQ counters of a profile run of THIS engine build, DESIGN.md §4); "
+                                 "null when no such run is committed"},
             "whole_path": {"input_GBps_over_kernel_time": round(n_local / (ksum / 1e3) / 1e9, 2) if ksum else None,
                            "frac_of_hbm_peak": round(n_local / (ksum / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if ksum else None},
             "dominant_kernel_own_traffic": {"bytes_per_input_byte": round(alg[dom], 4),
                                             "GBps": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9, 2) if kern[dom] > 0 else None,
                                             "frac_of_hbm_peak": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if kern[dom] > 0 else None},
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
+            "clocks": {"before": clocks_before, "after": clocks_after, "source": "rocm-smi -d 0 --showclocks --showpower --showperflevel --json"},
             "output_checked_bit_exact": ok, "output_bytes_checked": checked,
         }
         if not a.no_cpu and world == 1:

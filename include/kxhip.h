@@ -60,7 +60,11 @@ typedef struct kx_stats {
   uint32_t emit_overflow_pieces; /* output stage: pieces that needed a second sweep (last stage run) */
 } kx_stats;
 
-/* tuning knobs (0 = default) */
+/* tuning knobs (0 = default, in every field).  Round 6: what used to be environment variables of the library (KX_DF, KX_DF_K, KX_INL,
+ * KX_JL, KX_EMIT_*, KX_NO_*, KX_FORCE_*, KX_ACT_*, KX_DEBUG_FLAGS) is here; the library itself reads only KX_DEBUG (chatter on stderr),
+ * KX_FD_TRACE, KX_WINDOW_BYTES and KX_READ_THREADS (kx_run_fd's host side).  The produced binary (kxrun.cpp) and the Python test
+ * binding (kleenexlang_amd/host.py) map the old variable names onto this struct, so scripts keep working.
+ * LOAD-TIME fields decide how the tables are built: they take effect in kx_load_config; kx_set_config refuses to change them. */
 typedef struct kx_config {
   uint32_t segment_bytes;  /* input bytes per lane; multiple of 64; 0 = one round of lanes (4-64 KiB)  */
   uint32_t block_threads;  /* workgroup size (power of two); default 512        */
@@ -69,15 +73,50 @@ typedef struct kx_config {
   uint64_t window_bytes;   /* kx_run_fd: input bytes resident at a time; 0 = 1 GiB (env KX_WINDOW_BYTES overrides;
                               KX_READ_THREADS = pread threads per chunk of a regular file, default 4; KX_FD_TRACE=1 prints where
                               the reader / compute / writer threads spent their time) */
+  /* ---- which engine (load time) ---- */
+  uint32_t delayed_form;   /* 0 auto (taken where at most a quarter of the start-reachable transitions are undecided), 1 never,
+                              2 whatever that share                                                          [KX_DF=0 / 2] */
+  uint32_t delay;          /* 0 auto (1 where one symbol decides everything the start state reaches, else 2), 1, 2   [KX_DF_K] */
+  uint32_t merge_window;   /* merged constants (kx_delayed.h): 0 auto (the largest J <= 8 whose table image leaves k_dforward two
+                              blocks per CU), else J = merge_window - 1 (1: none)                                   [KX_DF_J = J] */
+  uint32_t inline_consts;  /* general engine, inline-constant entry layout: 0 auto, 1 off, 2 on                    [KX_INL=0 / 1] */
+  uint32_t job_stride;     /* general engine, job-stride entry layout: 0 auto (a second image, chosen shard by shard from the
+                              constants per piece), 1 off, 2 on (only that image)                [KX_JL_AUTO_OFF / KX_JL=0 / 1] */
+  uint32_t disable;        /* KX_OFF_* bits                                                                             */
+  uint32_t force;          /* KX_FORCE_* bits                                                                           */
+  /* ---- the output stage's plan (run time) ---- */
+  uint32_t emit_waves;     /* waves per CU of k_emit / k_demit: 0 auto (12), 4, 8, 12, 16 (16: delayed form only)   [KX_EMIT_WAVES] */
+  uint32_t emit_half;      /* k_demit, a lane takes half a piece: 0 auto (where 64 pieces outgrow a wave's staging), 1 off, 2 on [KX_EMIT_HALF] */
+  uint32_t emit_inplace;   /* k_emit, constants copied by the sweeping lane instead of jobs: 0 auto, 1 off, 2 on    [KX_EMIT_INPLACE] */
+  uint32_t emit_staging;   /* k_emit, staging bytes per wave: 0 auto                                                 [KX_EMIT_STG] */
+  uint32_t df_backoff;     /* after a shard left the delayed form: 0 = the stage skips 2^k - 1 shards after the k-th fall-back in a
+                              row (at most 63), 1 = every shard tries the form again                                        */
+  uint32_t debug_flags;    /* 64: per-phase shader-clock timeline of k_emit / k_demit (printed under KX_DEBUG)     [KX_DEBUG_FLAGS] */
+  /* ---- the action post-pass (run time) ---- */
+  uint32_t act_par_min;    /* bytes from which a token stream is replayed chunk-parallel: 0 = 1 MiB                 [KX_ACT_PAR_MIN] */
+  uint32_t act_prefix3_min;/* blocks from which the safe-point prefix runs in three steps: 0 = 65536             [KX_ACT_PREFIX3_MIN] */
+  uint32_t act_lanes;      /* one lane per chunk (token-dense streams): 0 auto, 1 off, 2 on                           [KX_ACT_LANES] */
+  uint32_t act_chunk;      /* wanted chunk bytes: 0 auto (2048 / 4096)                                                 [KX_ACT_CHUNK] */
+  uint32_t reserved[4];    /* must be 0 */
 } kx_config;
+#define KX_OFF_DIRECT 1u     /* load: entries of the plain layout name their action, not the constant's pool slot    [KX_NO_DIRECT] */
+#define KX_OFF_PAIR 2u       /* load: no two-symbol table for k_forward                                                 [KX_NO_PAIR] */
+#define KX_OFF_CMPX 4u       /* load: constants of at most 16 bytes are not stored by the v_cmpx sequences              [KX_NO_CMPX] */
+#define KX_OFF_COOP 8u       /* run:  k_forward without cooperative line loads                                          [KX_NO_COOP] */
+#define KX_FORCE_BIG 1u      /* load: tables stay in global memory whatever their size (the BIG instances; tests)     [KX_FORCE_BIG] */
+#define KX_FORCE_TBLMODE 2u  /* load: per-entry symbol-table ids even where one table would do (tests)            [KX_FORCE_TBLMODE] */
+#define KX_FORCE_ACT_SEQ 4u  /* run:  the action post-pass on one wave                                                  [KX_ACT_SEQ] */
+#define KX_FORCE_SAME_DEVICE 8u /* kx_run_fd_sharded_cfg: every rank on the caller's current device (a one-GPU box)  [KX_SHARD_SAME_DEVICE] */
 
-int kx_load(const void* blob, size_t blob_len, kx_program** prog);
+int kx_load(const void* blob, size_t blob_len, kx_program** prog);   /* = kx_load_config(blob, blob_len, NULL, prog) */
+/* kx_load with the load-time fields of `cfg` (NULL: all defaults); its run-time fields become the program's configuration. */
+int kx_load_config(const void* blob, size_t blob_len, const kx_config* cfg, kx_program** prog);
 /* Structural check of a blob without touching a device: every section inside the blob, every index inside its table,
  * the engine's size limits.  0 or KX_E_BLOB (kx_load performs the same checks). */
 int kx_validate(const void* blob, size_t blob_len);
 void kx_free(kx_program* prog);
 const char* kx_last_error(void);
-int kx_set_config(kx_program* prog, const kx_config* cfg);
+int kx_set_config(kx_program* prog, const kx_config* cfg);   /* run-time fields; KX_E_ARG if a load-time field differs from what the program was loaded with */
 uint32_t kx_num_stages(const kx_program* prog);
 /* 1: the stage uses register actions (`r@t`, `!r`, `[r <- …]`).  Its transducer output is a token stream (kxp_format.h) that
  * kx_run_device / kx_run_host / kx_run_fd replay with the action post-pass before it leaves the stage; the replay is
@@ -89,10 +128,9 @@ int kx_stage_has_actions(const kx_program* prog, uint32_t stage);
  * Where every step's output is decided by at most K further input symbols the engine runs the stage as a forward transducer
  * with fixed delay K — a forward pass for the lengths and one fused walk that places the bytes; no backward pass.  A context
  * that K symbols do not decide is noticed at run time and the shard is redone by the general engine (and the stage backs off
- * from the form for a while): results never depend on which engine ran.  Environment: KX_DF=0 switches the delayed form off,
- * KX_DF=2 takes it whatever the share of undecided contexts, KX_DF_K=1|2 pins the delay (default: 1 where one symbol decides every
- * transition the start state reaches, else 2).
- * kx_df_describe needs no device: it builds the form from the blob (as kx_load does) and reports it; `image`, if not NULL,
+ * from the form for a while): results never depend on which engine ran.  kx_config::delayed_form / delay / merge_window select it.
+ * kx_df_describe needs no device: it builds the form from the blob (as kx_load does; the `_cfg` variants with the load-time fields of a
+ * configuration, the plain ones with the defaults) and reports it; `image`, if not NULL,
  * receives up to image_cap bytes of the table image (class*8 u8[256] — the class index where a stage has more than 31 byte classes — | rows of C x {lo = handle of the next state's row,
  * hi = what the step writes: bit 0 no byte copied, bits 10-22 pool offset/16 of the constant, bit 23 a constant follows,
  * bits 24-30 bytes appended} | pool).  kx_df_pending: what slot j (0 = oldest) of product state `state` still owes, per leaf
@@ -106,14 +144,30 @@ typedef struct kx_df_info {
   uint32_t image_bytes, off_pool, start_handle, dead_handle, escape_handle;
   uint32_t transitions, escapes;               /* over the whole table */
   uint32_t transitions_start, escapes_start;   /* over the part reachable from the program's start state */
+  uint32_t merge_window;   /* J: steps a constant may wait to be written together with the next one (0: no merged constants) */
   char reason[96];         /* why not, if available == 0 */
 } kx_df_info;
 int kx_df_describe(const void* blob, size_t blob_len, uint32_t stage, kx_df_info* info, void* image, size_t image_cap);
 int kx_df_pending(const void* blob, size_t blob_len, uint32_t stage, uint32_t state, uint32_t slot, uint32_t* sst_state,
                   uint32_t* kinds, uint32_t* n_out);
+int kx_df_describe_cfg(const void* blob, size_t blob_len, uint32_t stage, const kx_config* cfg, kx_df_info* info, void* image, size_t image_cap);
+int kx_df_pending_cfg(const void* blob, size_t blob_len, uint32_t stage, const kx_config* cfg, uint32_t state, uint32_t slot,
+                      uint32_t* sst_state, uint32_t* kinds, uint32_t* n_out);
+/* Merged constants (round 6): a constant may wait up to J = merge_window steps for the next one as long as no copied byte can come
+ * between them, so that one job of the output stage places both (apache_log: 15 constants per line become 8).  A product state then
+ * also holds the constants that are DUE; kx_df_deferred returns their bytes, oldest first (a shard's tail writes them in front of
+ * what the pending steps append).  *n_out = their length (which may exceed cap; at most cap bytes are stored). */
+int kx_df_deferred(const void* blob, size_t blob_len, uint32_t stage, const kx_config* cfg, uint32_t state, void* bytes, size_t cap, size_t* n_out);
+/* The handle of (SST state q, nothing pending, nothing due): where a segment, a window or a shard may begin.  *handle = 0xFFFF where
+ * the table does not hold it (the part reachable from the start state never visits q). */
+int kx_df_start_of_state(const void* blob, size_t blob_len, uint32_t stage, const kx_config* cfg, uint32_t sst_state, uint32_t* handle);
 /* of a loaded program: 0 the stage has no delayed form, 1 its next shard runs on it, 2 a shard gave it up (escape) and the stage is backing
- * off: after the k-th fall-back in a row the next 2^k - 1 shards (at most 63) go straight to the general engine, then the form is tried again */
+ * off: after the k-th fall-back in a row the next 2^k - 1 shards (at most 63) go straight to the general engine, then the form is tried again
+ * (kx_config::df_backoff = 1: at once); 3 a shard left the form in (nearly) every segment (at least one lane in 16, and 8 lanes): the
+ * program's output hangs on unbounded lookahead and the stage stays on the general engine until kx_stage_reset_delayed_form */
 int kx_stage_delayed_form(const kx_program* prog, uint32_t stage);
+/* forget the back-off: the stage's next shard tries the delayed form again (no-op for a stage without one) */
+void kx_stage_reset_delayed_form(kx_program* prog, uint32_t stage);
 
 /* Whole program (all pipeline stages) over one device-resident input.
  * d_out may be NULL with cap 0 to query the exact output size (returned in
@@ -191,6 +245,7 @@ int kx_run_sharded(kx_program* prog, int rank, int world, kx_allgather_fn ag, vo
  * The return code is collective (kx_run_sharded): a rank that fails locally says so in the next exchange and every rank
  * returns — its own code and message, or KX_E_IO naming the failing rank. */
 int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, int out_fd, kx_stats* stats);
+int kx_run_fd_sharded_cfg(const void* blob, size_t blob_len, const kx_config* cfg, int ngpus, int in_fd, int out_fd, kx_stats* stats);
 
 typedef struct kx_comm kx_comm;
 int kx_comm_unique_id(void* id128);

@@ -22,6 +22,16 @@
 // shard is redone by the general engine — exactness never rests on the delayed form being applicable.
 // At the end of a shard the K pending functions are evaluated at the shard's end leaf (the same hand-off value the general
 // engine uses; at end of input the final state's leaf) and written behind the kernel's output by the host ("tail").
+//
+// MERGED CONSTANTS (round 6).  A constant costs k_demit a job (a slot, a lane of its constants phase) however short it is, and the
+// path form cuts a program's constants where its STEPS fall: apache_log writes `"` `,` `"date":"` on three steps of which none
+// copies a byte in between — 15 constants per line where 8 would do.  A constant may wait as long as no copied byte can come
+// between it and the next one: the product state carries a queue `def` of constants that are due, each with its age; a step
+// whose successor cannot copy (no kind in the new oldest pending slot has the copy bit) keeps the queue, any other step writes
+// all of it in front of its own constant, and a constant that has waited J steps is written whatever follows.  Each constant's
+// step is thus a function of the J steps behind it alone: a lane that starts K + J symbols before its own part is in the same
+// product state as the run that came from the start of the input — the argument that lets a segment, a window or a shard begin
+// in (q, nothing pending, nothing due).  A shard's tail writes what is still due in front of the pending steps.
 // The reference has no counterpart: its SST parks undecided output in registers (SymbolicSST.hs:400-446, crt.c append/concat).
 #ifndef KX_DELAYED_H
 #define KX_DELAYED_H
@@ -40,17 +50,19 @@ constexpr uint32_t DF_MAX_K = 4;
 using Kind = uint32_t;
 using Slot = std::vector<Kind>;           // size 1: resolved value; else one kind per leaf of the state
 
-struct DfState { uint32_t q; std::vector<Slot> pend; };
+struct DfState { uint32_t q; std::vector<Slot> pend; std::vector<std::pair<uint32_t, uint32_t>> def; };   // def: (canonical path-constant id, age) still due, oldest first
 
 struct DfBuild {
   uint32_t K = 0, C = 0, nP = 0;
+  uint32_t J = 0;                          // merge window: steps a constant may wait for the next one (0: every constant is written on its own step)
+  std::vector<std::string> outs;           // what a step writes behind its copied byte (merged constants included); outs[0] = nothing
   bool wide = false;                       // more than 31 byte classes: the class table holds class indices (else class * 8)
   std::vector<uint32_t> img;               // LDS image: [class*8 u8[256] | rows (nP + 2) x C x {lo, hi} | pool]
   // pool: every path constant FOUR times — copy s = the constant from its byte s on, zero-padded to plen = (length + 15) & ~15
   // bytes, the copies one behind the other from a 16-byte boundary — so that k_demit can store the part of a constant behind the
   // next 4-byte boundary of its destination as ALIGNED DWORDS fetched with one aligned 16-byte read (copy s, s = bytes up to
   // that boundary); an entry names copy 0
-  std::vector<uint32_t> pool_off;          // [npc] offset of copy 0 inside the pool
+  std::vector<uint32_t> pool_off;          // [outs.size()] offset of copy 0 inside the pool
   uint32_t off_pool = 0, deadh = 0, esch = 0, starth = 0;
   std::vector<uint16_t> start_of_state;    // [nstates] handle of (q, nothing pending); 0xFFFF = not in the table
   std::vector<DfState> states;             // host copy: original state and pending functions of every product state
@@ -71,7 +83,7 @@ struct DfInput {   // views into a parsed stage (kx_engine.hip: parseStage)
 };
 
 // Returns "" and fills `out`, or the reason why the stage has no delayed form.
-inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budget, DfBuild& out) {
+inline std::string buildDelayed(const DfInput& in, uint32_t K, uint32_t J, size_t image_budget, DfBuild& out) {
   const uint32_t C = in.C, Lm = in.Lm;
   if (K == 0 || K > DF_MAX_K) return "delay out of range";
   if (in.has_tbl) return "symbol tables";
@@ -100,11 +112,19 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   auto keyOf = [](const DfState& s) {
     std::vector<uint32_t> k; k.push_back(s.q);
     for (auto& sl : s.pend) { k.push_back((uint32_t)sl.size()); k.insert(k.end(), sl.begin(), sl.end()); }
+    k.push_back(0xFFFFFFFEu);
+    for (auto& d : s.def) { k.push_back(d.first); k.push_back(d.second); }
     return k;
   };
+  // what a step writes behind its copied byte, interned by content
+  out.outs.assign(1, std::string());
+  std::map<std::string, uint32_t> out_ids; out_ids.emplace(std::string(), 0u);
+  auto outId = [&](const std::string& t) { auto it = out_ids.find(t); if (it != out_ids.end()) return it->second; const uint32_t id = (uint32_t)out.outs.size(); out_ids.emplace(t, id); out.outs.push_back(t); return id; };
+  auto bytesOf = [&](uint32_t pc) { return pc < in.npc ? std::string((const char*)in.pcpool + in.pcoff[pc], clen[pc]) : std::string(); };
+  bool too_long = false;
   const size_t row_bytes = (size_t)C * 8;
   size_t maxP = (65536 - DF_OFF_ROWS) / row_bytes;
-  const size_t pool_est = 4 * (size_t)in.apool_bytes + 64;   // (four copies of every constant)
+  const size_t pool_est = 4 * (size_t)in.apool_bytes + 64 + (J ? 2048 : 0);   // (four copies of every constant; merged ones on top)
   if (image_budget > DF_OFF_ROWS + pool_est + 3 * row_bytes) {
     const size_t byb = (image_budget - DF_OFF_ROWS - pool_est) / row_bytes;
     if (byb < maxP) maxP = byb;
@@ -123,13 +143,13 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
     ids.emplace(std::move(k), id); S.push_back(std::move(st)); todo.push_back(id);
     return id;
   };
-  struct Tr { int64_t next; Kind emit; };   // next: state index, -1 = no transition (dead), -2 = escape
+  struct Tr { int64_t next; uint32_t copy, out; };   // next: state index, -1 = no transition (dead), -2 = escape; what the step writes: the copied byte?, outs[out]
   std::vector<std::vector<Tr>> trans;
   auto expand = [&]() {
     while (!todo.empty()) {
       const uint32_t id = todo.back(); todo.pop_back();
       if (trans.size() <= id) trans.resize(id + 1);
-      std::vector<Tr> row(C, Tr{-1, NOTHING});
+      std::vector<Tr> row(C, Tr{-1, 0, 0});
       for (uint32_t c = 0; c < C; ++c) {
         const DfState cur = S[id];   // (copy: S may grow)
         const uint16_t t = in.delta[(size_t)cur.q * C + c];
@@ -151,10 +171,11 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
           if (!ok) { np.clear(); break; }
           // dead leaves take the value of any live one (they cannot be the end leaf)
           Kind live = 0xFFFFFFFFu; for (Kind k : h) if (k != 0xFFFFFFFFu) { live = k; break; }
+          if (live == 0xFFFFFFFFu) live = NOTHING;   // (every leaf of the target dead: nothing survives to ask, as for g_new below)
           for (Kind& k : h) if (k == 0xFFFFFFFFu) k = live;
           normalise(h); np.push_back(std::move(h));
         }
-        if (np.size() != cur.pend.size()) { row[c] = Tr{-2, NOTHING}; ++out.nesc; continue; }
+        if (np.size() != cur.pend.size()) { row[c] = Tr{-2, 0, 0}; ++out.nesc; continue; }
         {
           Slot h(nl);
           Kind live = 0xFFFFFFFFu;
@@ -163,12 +184,25 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
           for (Kind& k : h) if (k == 0xFFFFFFFFu) k = live;
           normalise(h); np.push_back(std::move(h));
         }
-        if (np[0].size() != 1) { row[c] = Tr{-2, NOTHING}; ++out.nesc; continue; }   // K symbols do not decide step s-K
+        if (np[0].size() != 1) { row[c] = Tr{-2, 0, 0}; ++out.nesc; continue; }   // K symbols do not decide step s-K
         const Kind emit = np[0][0];
         nx.pend.assign(np.begin() + 1, np.end());
+        // the constants due: those that waited, then this step's own.  (A state with constants due never copies: they were kept
+        // because no kind of the slot that is resolved NOW had the copy bit, and composing with a parent map only selects among them.)
+        std::vector<std::pair<uint32_t, uint32_t>> due = cur.def;
+        if ((emit >> 1) < in.npc && clen[emit >> 1]) due.emplace_back(canon[emit >> 1], 0u);
+        bool next_may_copy = J == 0;
+        for (Kind k : nx.pend[0]) next_may_copy = next_may_copy || (k & 1u);
+        std::string text;
+        size_t nout = due.size();
+        if (!next_may_copy) { nout = 0; while (nout < due.size() && due[nout].second >= J) ++nout; }
+        for (size_t i = 0; i < nout; ++i) text += bytesOf(due[i].first);
+        for (size_t i = nout; i < due.size(); ++i) nx.def.emplace_back(due[i].first, due[i].second + 1);
+        if (text.size() + 1 > 126) { too_long = true; text.resize(125); }
+        const uint32_t oid = outId(text);
         const int64_t ni = add(std::move(nx));
-        if (ni < 0) { row[c] = Tr{-2, NOTHING}; ++out.nesc; ++out.capped; continue; }
-        row[c] = Tr{ni, emit}; ++out.ntrans;
+        if (ni < 0) { row[c] = Tr{-2, 0, 0}; ++out.nesc; ++out.capped; continue; }
+        row[c] = Tr{ni, emit & 1u, oid}; ++out.ntrans;
       }
       trans[id] = std::move(row);
     }
@@ -199,8 +233,9 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
     }
     expand();
   }
+  if (too_long) return "a merged constant longer than 125 bytes";
   const uint32_t nP = (uint32_t)S.size();
-  out.K = K; out.C = C; out.nP = nP;
+  out.K = K; out.C = C; out.nP = nP; out.J = J;
   out.deadh = out.handleOf(nP); out.esch = out.handleOf(nP + 1); out.starth = out.handleOf(0);
   for (uint32_t q = 0; q < in.nstates; ++q) if (out.start_of_state[q] != 0xFFFFu) {
     DfState st; st.q = q; for (uint32_t j = 0; j < K; ++j) st.pend.push_back(Slot{NOTHING});
@@ -210,15 +245,15 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   const size_t rows_end = DF_OFF_ROWS + (size_t)(nP + 2) * row_bytes;
   const size_t off_pool = (rows_end + 15) & ~(size_t)15;
   std::vector<uint8_t> pool;
-  out.pool_off.assign(in.npc, 0);
-  for (uint32_t pc = 0; pc < in.npc; ++pc) {
-    if (canon[pc] != pc) { out.pool_off[pc] = out.pool_off[canon[pc]]; continue; }
-    const uint32_t L = clen[pc], plen = (L + 15) & ~15u;
-    out.pool_off[pc] = (uint32_t)pool.size();
+  out.pool_off.assign(out.outs.size(), 0);
+  for (size_t oi = 1; oi < out.outs.size(); ++oi) {
+    const std::string& t = out.outs[oi];
+    const uint32_t L = (uint32_t)t.size(), plen = (L + 15) & ~15u;
+    out.pool_off[oi] = (uint32_t)pool.size();
     for (uint32_t sft = 0; sft < 4; ++sft) {
       const size_t at = pool.size();
       pool.resize(at + plen, 0);
-      if (sft < L) memcpy(&pool[at], in.pcpool + in.pcoff[pc] + sft, L - sft);
+      if (sft < L) memcpy(&pool[at], t.data() + sft, L - sft);
     }
   }
   pool.resize(pool.size() + 32, 0);   // (reads of 16 bytes behind the last copy stay inside)
@@ -228,11 +263,10 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
   out.img.assign((off_pool + pool.size() + 3) / 4, 0u);
   uint8_t* ib = (uint8_t*)out.img.data();
   for (int b = 0; b < 256; ++b) ib[b] = (uint8_t)(out.wide ? in.cls[b] : in.cls[b] * 8);
-  auto entryHi = [&](Kind k) -> uint32_t {
-    const uint32_t copy = k & 1u, pc = k >> 1;
-    const uint32_t cl = pc < in.npc ? clen[pc] : 0u;
+  auto entryHi = [&](uint32_t copy, uint32_t oid) -> uint32_t {
+    const uint32_t cl = (uint32_t)out.outs[oid].size();
     uint32_t e = (copy ? 0u : 1u) | ((cl + copy) << 24);
-    if (cl) e |= ((out.pool_off[pc] >> 4) << 10) | (1u << 23);
+    if (cl) e |= ((out.pool_off[oid] >> 4) << 10) | (1u << 23);
     return e;
   };
   uint32_t* rows = out.img.data() + DF_OFF_ROWS / 4;
@@ -242,7 +276,7 @@ inline std::string buildDelayed(const DfInput& in, uint32_t K, size_t image_budg
       if (i >= nP) lo = out.handleOf(i);
       else {
         const Tr& t = trans[i][c];
-        if (t.next == -1) lo = out.deadh; else if (t.next == -2) lo = out.esch; else { lo = out.handleOf((uint32_t)t.next); hi = entryHi(t.emit); }
+        if (t.next == -1) lo = out.deadh; else if (t.next == -2) lo = out.esch; else { lo = out.handleOf((uint32_t)t.next); hi = entryHi(t.copy, t.out); }
       }
       // the upper half of lo repeats what the measuring pass adds up in ONE add: bytes appended << 8 | 4 x "a constant follows"
       lo |= (hi & 0xFF000000u) | (((hi >> 23) & 1u) << 18);

@@ -319,6 +319,7 @@ static int runSharded(kx_program* p, int rank, int world, kx_allgather_fn ag, vo
     if (st + 1 == ns && world > 1) {
       LenMsg mine{0, err ? 1u : 0u, 0u};
       rc = gather(&mine, lens.data(), sizeof(LenMsg));
+      res->boundary_ms = (float)boundary;   // (this exchange is part of the hand-off time, also on the ways out below)
       if (rc) return rc;
       if ((rc = collective(lens))) return rc;
     } else if (st + 1 == ns && err) { res->boundary_ms = (float)boundary; return sErr(err, err_msg); }
@@ -336,9 +337,13 @@ int kx_run_sharded(kx_program* p, int rank, int world, kx_allgather_fn ag, void*
 
 // `BIN --gpus N < file > out`: the input (a regular file) cut into N contiguous shards at 4 KiB multiples, one thread and
 // one program instance per GPU, the hand-off among the threads through host memory; every rank writes its slice of the
-// output at its own offset (a regular file) or in rank order (a pipe).  KX_SHARD_SAME_DEVICE=1 stacks the ranks on the
-// current device (validation on a one-GPU box).
+// output at its own offset (a regular file) or in rank order (a pipe).  kx_config::force & KX_FORCE_SAME_DEVICE stacks the ranks on
+// the current device (validation on a one-GPU box; the produced binary maps KX_SHARD_SAME_DEVICE=1 onto it).
 int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, int out_fd, kx_stats* stats) {
+  return kx_run_fd_sharded_cfg(blob, blob_len, nullptr, ngpus, in_fd, out_fd, stats);
+}
+
+int kx_run_fd_sharded_cfg(const void* blob, size_t blob_len, const kx_config* cfg, int ngpus, int in_fd, int out_fd, kx_stats* stats) {
   if (!blob || ngpus < 1) return sErr(KX_E_ARG, "bad arguments");
   struct stat sti, sto;
   if (fstat(in_fd, &sti) || !S_ISREG(sti.st_mode)) return sErr(KX_E_ARG, "--gpus needs a regular file on stdin (each GPU reads its own shard)");
@@ -346,7 +351,7 @@ int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, i
   const off_t out_base = out_seekable ? lseek(out_fd, 0, SEEK_CUR) : 0;   // (output starts where the descriptor stands)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sErr(KX_E_HIP, "no HIP device available: the engine has no CPU fallback");
-  const bool same = getenv("KX_SHARD_SAME_DEVICE") != nullptr;
+  const bool same = cfg && (cfg->force & KX_FORCE_SAME_DEVICE);
   if (!same && ngpus > ndev) return sErr(KX_E_ARG, "--gpus " + std::to_string(ngpus) + " but " + std::to_string(ndev) + " visible device(s)");
   const uint64_t n = (uint64_t)sti.st_size;
   const uint64_t L = ngpus > 1 ? (n / ngpus) / 4096 * 4096 : n;
@@ -362,7 +367,7 @@ int kx_run_fd_sharded(const void* blob, size_t blob_len, int ngpus, int in_fd, i
     const uint64_t start = (uint64_t)r * L, len = r == ngpus - 1 ? n - start : L;
     kx_program* prog = nullptr; void *d_in = nullptr, *d_out = nullptr; std::vector<char> host;
     kx_group_member* mb = kx_group_join(grp, r);
-    if (!rcs[r] && kx_load(blob, blob_len, &prog)) fail(KX_E_BLOB, kx_last_error());
+    if (!rcs[r] && kx_load_config(blob, blob_len, cfg, &prog)) fail(KX_E_BLOB, kx_last_error());
     if (!rcs[r]) {
       host.resize(len ? len : 1);
       uint64_t got = 0;

@@ -26,6 +26,38 @@
 
 #include "../../../include/kxhip.h"
 
+// The engine's switches are fields of kx_config (include/kxhip.h); the library reads no environment variable for them.  A produced
+// binary keeps honouring the variable names that earlier rounds' scripts use: they are read HERE, once, and mapped onto the struct.
+static kx_config configFromEnv() {
+  kx_config c{};
+  auto num = [](const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; };
+  auto tri = [&](const char* name) -> uint32_t { const char* e = getenv(name); return !e ? 0u : atoi(e) ? 2u : 1u; };   // unset: auto, 0: off, else: on
+  if (const char* e = getenv("KX_DF")) { const int v = atoi(e); c.delayed_form = v == 0 ? 1u : v == 2 ? 2u : 0u; }
+  c.delay = (uint32_t)num("KX_DF_K", 0);
+  if (getenv("KX_DF_J")) c.merge_window = (uint32_t)num("KX_DF_J", 0) + 1;
+  c.inline_consts = tri("KX_INL");
+  c.job_stride = getenv("KX_JL") ? tri("KX_JL") : getenv("KX_JL_AUTO_OFF") ? 1u : 0u;
+  if (getenv("KX_NO_DIRECT")) c.disable |= KX_OFF_DIRECT;
+  if (getenv("KX_NO_PAIR")) c.disable |= KX_OFF_PAIR;
+  if (getenv("KX_NO_CMPX")) c.disable |= KX_OFF_CMPX;
+  if (getenv("KX_NO_COOP")) c.disable |= KX_OFF_COOP;
+  if (getenv("KX_FORCE_BIG")) c.force |= KX_FORCE_BIG;
+  if (getenv("KX_FORCE_TBLMODE")) c.force |= KX_FORCE_TBLMODE;
+  if (getenv("KX_ACT_SEQ")) c.force |= KX_FORCE_ACT_SEQ;
+  if (getenv("KX_SHARD_SAME_DEVICE")) c.force |= KX_FORCE_SAME_DEVICE;
+  c.emit_waves = (uint32_t)num("KX_EMIT_WAVES", 0);
+  c.emit_half = tri("KX_EMIT_HALF");
+  c.emit_inplace = tri("KX_EMIT_INPLACE");
+  c.emit_staging = (uint32_t)num("KX_EMIT_STG", 0);
+  c.df_backoff = (uint32_t)num("KX_DF_BACKOFF_OFF", 0) ? 1u : 0u;
+  c.debug_flags = (uint32_t)num("KX_DEBUG_FLAGS", 0);
+  c.act_par_min = (uint32_t)num("KX_ACT_PAR_MIN", 0);
+  c.act_prefix3_min = (uint32_t)num("KX_ACT_PREFIX3_MIN", 0);
+  c.act_lanes = tri("KX_ACT_LANES");
+  c.act_chunk = (uint32_t)num("KX_ACT_CHUNK", 0);
+  return c;
+}
+
 static void usage(const char* name) {
   fprintf(stdout, "Normal usage: %s < infile > outfile\n", name);
   fprintf(stdout, "- \"%s\": reads from stdin and writes to stdout.\n", name);
@@ -81,26 +113,26 @@ int main(int argc, char** argv) {
   std::string lib = env ? env : libdir + "/libkxhip.so";
   void* h = dlopen(lib.c_str(), RTLD_NOW);
   if (!h) { fprintf(stderr, "%s: cannot load the HIP engine: %s\n", argv[0], dlerror()); return 1; }
-  auto load = (int (*)(const void*, size_t, kx_program**))dlsym(h, "kx_load");
+  auto load = (int (*)(const void*, size_t, const kx_config*, kx_program**))dlsym(h, "kx_load_config");
   auto run = (int (*)(kx_program*, int, int, kx_stats*))dlsym(h, "kx_run_fd");
   auto lasterr = (const char* (*)(void))dlsym(h, "kx_last_error");
   if (!load || !run || !lasterr) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
   kx_stats st;
   int rc;
+  kx_config cfg = configFromEnv();
   if (gpus) {
-    auto runs = (int (*)(const void*, size_t, int, int, int, kx_stats*))dlsym(h, "kx_run_fd_sharded");
+    auto runs = (int (*)(const void*, size_t, const kx_config*, int, int, int, kx_stats*))dlsym(h, "kx_run_fd_sharded_cfg");
     if (phase) { fprintf(stderr, "%s: --gpus cannot be combined with --phase\n", argv[0]); return 1; }
-    if (!runs) { fprintf(stderr, "%s: this libkxhip.so has no kx_run_fd_sharded (--gpus needs the engine library of round 3 or later)\n", argv[0]); return 1; }
-    rc = runs(blob.data(), blob.size(), (int)gpus, STDIN_FILENO, STDOUT_FILENO, &st);
+    if (!runs) { fprintf(stderr, "%s: this libkxhip.so has no kx_run_fd_sharded_cfg (--gpus needs the engine library of round 6 or later)\n", argv[0]); return 1; }
+    rc = runs(blob.data(), blob.size(), &cfg, (int)gpus, STDIN_FILENO, STDOUT_FILENO, &st);
   } else {
   kx_program* prog = nullptr;
-  if (load(blob.data(), blob.size(), &prog)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
+  if (load(blob.data(), blob.size(), &cfg, &prog)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
   if (phase) {
     auto setcfg = (int (*)(kx_program*, const kx_config*))dlsym(h, "kx_set_config");
     auto nst = (uint32_t (*)(const kx_program*))dlsym(h, "kx_num_stages");
     if (!setcfg || !nst) { fprintf(stderr, "%s: engine library lacks required symbols\n", argv[0]); return 1; }
     if ((unsigned long)phase > nst(prog)) { fprintf(stderr, "Invalid phase: %ld given\n", phase); return 1; }   // (crt.c match(): default case)
-    kx_config cfg{};
     cfg.phase = (uint32_t)phase;
     if (setcfg(prog, &cfg)) { fprintf(stderr, "%s: %s\n", argv[0], lasterr()); return 1; }
   }

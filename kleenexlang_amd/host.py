@@ -62,15 +62,67 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, 
 
 
 class KxConfig(ctypes.Structure):
+    """include/kxhip.h::kx_config (0 = default in every field)."""
     _fields_ = [("segment_bytes", ctypes.c_uint32), ("block_threads", ctypes.c_uint32),
-                ("collect_timing", ctypes.c_uint32), ("phase", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)]
+                ("collect_timing", ctypes.c_uint32), ("phase", ctypes.c_uint32), ("window_bytes", ctypes.c_uint64)] + \
+               [(k, ctypes.c_uint32) for k in ("delayed_form", "delay", "merge_window", "inline_consts", "job_stride", "disable", "force",
+                                               "emit_waves", "emit_half", "emit_inplace", "emit_staging", "df_backoff", "debug_flags",
+                                               "act_par_min", "act_prefix3_min", "act_lanes", "act_chunk")] + \
+               [("reserved", ctypes.c_uint32 * 4)]
+
+
+KX_OFF_DIRECT, KX_OFF_PAIR, KX_OFF_CMPX, KX_OFF_COOP = 1, 2, 4, 8
+KX_FORCE_BIG, KX_FORCE_TBLMODE, KX_FORCE_ACT_SEQ, KX_FORCE_SAME_DEVICE = 1, 2, 4, 8
+
+
+def config_from_env(env=None, **fields):
+    """The engine's switches are fields of kx_config; the library reads no environment variable for them.  Tests and profiling
+    scripts keep using the variable names of earlier rounds: they are read HERE (and in kxrun.cpp for produced binaries) and mapped
+    onto the struct.  `fields` override."""
+    env = os.environ if env is None else env
+    c = KxConfig()
+
+    def tri(name):      # unset: auto, 0: off, anything else: on
+        return 0 if name not in env else (2 if int(env[name]) else 1)
+
+    def num(name):
+        return int(env.get(name, "0") or 0)
+
+    if "KX_DF" in env:
+        v = int(env["KX_DF"])
+        c.delayed_form = 1 if v == 0 else 2 if v == 2 else 0
+    c.delay = num("KX_DF_K")
+    if "KX_DF_J" in env:
+        c.merge_window = int(env["KX_DF_J"]) + 1
+    c.inline_consts = tri("KX_INL")
+    c.job_stride = tri("KX_JL") if "KX_JL" in env else (1 if "KX_JL_AUTO_OFF" in env else 0)
+    for name, bit in (("KX_NO_DIRECT", KX_OFF_DIRECT), ("KX_NO_PAIR", KX_OFF_PAIR), ("KX_NO_CMPX", KX_OFF_CMPX), ("KX_NO_COOP", KX_OFF_COOP)):
+        if name in env:
+            c.disable |= bit
+    for name, bit in (("KX_FORCE_BIG", KX_FORCE_BIG), ("KX_FORCE_TBLMODE", KX_FORCE_TBLMODE), ("KX_ACT_SEQ", KX_FORCE_ACT_SEQ),
+                      ("KX_SHARD_SAME_DEVICE", KX_FORCE_SAME_DEVICE)):
+        if name in env:
+            c.force |= bit
+    c.emit_waves = num("KX_EMIT_WAVES")
+    c.emit_half = tri("KX_EMIT_HALF")
+    c.emit_inplace = tri("KX_EMIT_INPLACE")
+    c.emit_staging = num("KX_EMIT_STG")
+    c.df_backoff = 1 if num("KX_DF_BACKOFF_OFF") else 0
+    c.debug_flags = num("KX_DEBUG_FLAGS")
+    c.act_par_min = num("KX_ACT_PAR_MIN")
+    c.act_prefix3_min = num("KX_ACT_PREFIX3_MIN")
+    c.act_lanes = tri("KX_ACT_LANES")
+    c.act_chunk = num("KX_ACT_CHUNK")
+    for k, v in fields.items():
+        setattr(c, k, v)
+    return c
 
 
 class KxDfInfo(ctypes.Structure):
     """include/kxhip.h::kx_df_info — the delayed form of one stage."""
     _fields_ = [(k, ctypes.c_uint32) for k in ("available", "delay", "nstates", "nclasses", "image_bytes", "off_pool", "start_handle",
                                                "dead_handle", "escape_handle", "transitions", "escapes", "transitions_start",
-                                               "escapes_start")] + [("reason", ctypes.c_char * 96)]
+                                               "escapes_start", "merge_window")] + [("reason", ctypes.c_char * 96)]
 
 
 class KxFwdSummary(ctypes.Structure):
@@ -127,6 +179,9 @@ def load_engine():
         lib = ctypes.CDLL(path)
         vp, sz, u32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64
         lib.kx_load.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(vp)]
+        lib.kx_load_config.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(KxConfig), ctypes.POINTER(vp)]
+        lib.kx_stage_reset_delayed_form.argtypes = [vp, u32]
+        lib.kx_stage_reset_delayed_form.restype = None
         lib.kx_validate.argtypes = [ctypes.c_char_p, sz]
         lib.kx_free.argtypes = [vp]
         lib.kx_last_error.restype = ctypes.c_char_p
@@ -137,6 +192,11 @@ def load_engine():
         lib.kx_stage_delayed_form.argtypes = [vp, u32]
         lib.kx_df_describe.argtypes = [ctypes.c_char_p, sz, u32, ctypes.POINTER(KxDfInfo), vp, sz]
         lib.kx_df_pending.argtypes = [ctypes.c_char_p, sz, u32, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+        cfgp = ctypes.POINTER(KxConfig)
+        lib.kx_df_describe_cfg.argtypes = [ctypes.c_char_p, sz, u32, cfgp, ctypes.POINTER(KxDfInfo), vp, sz]
+        lib.kx_df_pending_cfg.argtypes = [ctypes.c_char_p, sz, u32, cfgp, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32)]
+        lib.kx_df_deferred.argtypes = [ctypes.c_char_p, sz, u32, cfgp, u32, ctypes.c_void_p, sz, ctypes.POINTER(sz)]
+        lib.kx_df_start_of_state.argtypes = [ctypes.c_char_p, sz, u32, cfgp, u32, ctypes.POINTER(u32)]
         lib.kx_run_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(KxStats), vp]
         lib.kx_run_host.argtypes = [vp, ctypes.c_char_p, sz, ctypes.POINTER(vp), ctypes.POINTER(sz),
                                     ctypes.POINTER(KxStats)]
@@ -297,31 +357,57 @@ def validate_blob(blob):
         raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
 
 
-def df_describe(blob, stage=0, with_image=True):
-    """The delayed form of a stage, built on the host (no device needed): (KxDfInfo, table image bytes or None)."""
+def df_describe(blob, stage=0, with_image=True, cfg=None):
+    """The delayed form of a stage, built on the host (no device needed): (KxDfInfo, table image bytes or None).
+    cfg: a KxConfig (its load-time fields); None = what the environment's KX_DF* variables say (config_from_env)."""
     lib = load_engine()
     blob = bytes(blob)
     info = KxDfInfo()
-    if lib.kx_df_describe(blob, len(blob), stage, ctypes.byref(info), None, 0):
+    cfg = config_from_env() if cfg is None else cfg
+    if lib.kx_df_describe_cfg(blob, len(blob), stage, ctypes.byref(cfg), ctypes.byref(info), None, 0):
         raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
     img = None
     if with_image and info.image_bytes:
         buf = ctypes.create_string_buffer(info.image_bytes)
-        lib.kx_df_describe(blob, len(blob), stage, ctypes.byref(info), buf, info.image_bytes)
+        lib.kx_df_describe_cfg(blob, len(blob), stage, ctypes.byref(cfg), ctypes.byref(info), buf, info.image_bytes)
         img = buf.raw
     return info, img
 
 
-def df_pending(blob, stage, state, slot):
+def df_pending(blob, stage, state, slot, cfg=None):
     """(SST state, [copy | path-constant id << 1 per leaf, or one value]) of a product state's pending slot."""
     lib = load_engine()
     blob = bytes(blob)
     kinds = (ctypes.c_uint32 * KX_MAX_LEAVES)()
     n = ctypes.c_uint32()
     q = ctypes.c_uint32()
-    if lib.kx_df_pending(blob, len(blob), stage, state, slot, ctypes.byref(q), kinds, ctypes.byref(n)):
+    cfg = config_from_env() if cfg is None else cfg
+    if lib.kx_df_pending_cfg(blob, len(blob), stage, ctypes.byref(cfg), state, slot, ctypes.byref(q), kinds, ctypes.byref(n)):
         raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
     return q.value, list(kinds[:n.value])
+
+
+def df_deferred(blob, stage, state, cfg=None):
+    """The constants a product state still has due (merged constants, kx_delayed.h): their bytes, oldest first."""
+    lib = load_engine()
+    blob = bytes(blob)
+    buf = ctypes.create_string_buffer(1024)
+    n = ctypes.c_size_t()
+    cfg = config_from_env() if cfg is None else cfg
+    if lib.kx_df_deferred(blob, len(blob), stage, ctypes.byref(cfg), state, buf, 1024, ctypes.byref(n)):
+        raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+    return buf.raw[:n.value]
+
+
+def df_start_of_state(blob, stage, sst_state, cfg=None):
+    """Handle of (state, nothing pending, nothing due) in the delayed form's table, or 0xFFFF."""
+    lib = load_engine()
+    blob = bytes(blob)
+    h = ctypes.c_uint32()
+    cfg = config_from_env() if cfg is None else cfg
+    if lib.kx_df_start_of_state(blob, len(blob), stage, ctypes.byref(cfg), sst_state, ctypes.byref(h)):
+        raise EngineError(lib.kx_last_error().decode("utf-8", "replace"))
+    return h.value
 
 
 class KexcIlProgram(ctypes.Structure):
@@ -415,14 +501,18 @@ def compile_file(path, opt=3):
 class Program:
     """A compiled Kleenex program loaded on the current HIP device."""
 
-    def __init__(self, blob, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0):
+    def __init__(self, blob, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0, config=None):
+        """config: a KxConfig; None = the environment's KX_* variables mapped onto one (config_from_env) — the library itself reads
+        none of them."""
         self._lib = load_engine()
         self._h = ctypes.c_void_p()
         self._blob = bytes(blob)
-        rc = self._lib.kx_load(self._blob, len(self._blob), ctypes.byref(self._h))
+        self._cfg = config_from_env() if config is None else config
+        self._cfg.segment_bytes, self._cfg.block_threads = segment_bytes, block_threads
+        self._cfg.collect_timing, self._cfg.window_bytes = 1 if collect_timing else 0, window_bytes
+        rc = self._lib.kx_load_config(self._blob, len(self._blob), ctypes.byref(self._cfg), ctypes.byref(self._h))
         if rc:
             raise EngineError(self._err())
-        self.configure(segment_bytes, block_threads, collect_timing, window_bytes)
         self.last_stats = None
 
     @classmethod
@@ -436,10 +526,18 @@ class Program:
     def _err(self):
         return self._lib.kx_last_error().decode("utf-8", "replace")
 
-    def configure(self, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0):
-        cfg = KxConfig(segment_bytes, block_threads, 1 if collect_timing else 0, 0, window_bytes)
+    def configure(self, segment_bytes=0, block_threads=0, collect_timing=False, window_bytes=0, **fields):
+        """Run-time fields (kx_set_config); a load-time field in `fields` that differs from the loaded program's is refused."""
+        cfg = self._cfg
+        cfg.segment_bytes, cfg.block_threads = segment_bytes, block_threads
+        cfg.collect_timing, cfg.window_bytes = 1 if collect_timing else 0, window_bytes
+        for k, v in fields.items():
+            setattr(cfg, k, v)
         if self._lib.kx_set_config(self._h, ctypes.byref(cfg)):
             raise EngineError(self._err())
+
+    def reset_delayed_form(self, stage=0):
+        self._lib.kx_stage_reset_delayed_form(self._h, stage)
 
     @property
     def num_stages(self):

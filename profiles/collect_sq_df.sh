@@ -5,6 +5,7 @@ TAG=${1:-sq}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+export GRAFT_REPO_ROOT=$R
 cd /tmp && export TMPDIR=/tmp
 rm -f /tmp/pmc_*.csv
 for c in ${SQC:-GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR}; do
@@ -25,7 +26,14 @@ for f in glob.glob("/tmp/pmc_*.csv"):
             acc[m.group(0)][0] += 1; acc[m.group(0)][1] += float(r["Counter_Value"])
     for k, (n, v) in acc.items():
         res[k][c] = v / n
-json.dump({"workload": "%s 2 GiB, per launch (device totals)" % os.environ.get("PROG", "apache_log"), "kernels": res}, open(out + "/sq_counters.json", "w"), indent=1)
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.getcwd()))
+try:
+    from kleenexlang_amd import build as kbuild
+    sha = kbuild.engine_sha()
+except Exception:
+    sha = None
+json.dump({"workload": "%s 2 GiB, per launch (device totals)" % os.environ.get("PROG", "apache_log"), "program": os.environ.get("PROG", "apache_log"),
+           "input_bytes": 2 * 2**30 // (32 << 20) * (32 << 20), "engine_sha": sha, "kernels": res}, open(out + "/sq_counters.json", "w"), indent=1)
 for k in [x for x in ("k_demit", "k_dforward", "k_emit", "k_backlen", "k_forward") if x in res]:
     d = res[k]
     cu = d["GRBM_GUI_ACTIVE"] / 8

@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--segment", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--escapes", type=int, default=0, help="(apache_log, 1 GPU) overwrite 7 bytes in that many evenly spaced request fields with "
+                                                            "\\\"   5x — a context that two symbols do not decide (an escaped quote); the output is then "
+                                                            "checked against the general engine's on the same input instead of the tiled oracle output")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded protocol even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the boundary hand-off")
     ap.add_argument("--single-device", action="store_true", help="(validation) put every rank on cuda:0")
@@ -188,6 +191,16 @@ def main():
         off = start % len(base)
         reps = (off + n_local + len(base) - 1) // len(base)
         t = tb.repeat(reps)[off:off + n_local].clone()   # fresh (16-byte aligned) allocation holding exactly the shard
+    n_escapes = 0
+    if a.escapes and world == 1 and a.program == "apache_log":
+        pat = torch.tensor(list(b'\\"   5x'), dtype=torch.uint8, device=dev)
+        for i in range(a.escapes):
+            at = int((i + 0.5) * n_local / a.escapes)
+            win = bytes(t[at:at + 4096].cpu().numpy().tobytes())
+            k = win.find(b' HTTP/')
+            if k >= 16 and b'"' not in win[k - 8:k] and b' ' not in win[k - 8:k]:
+                t[at + k - 7:at + k] = pat
+                n_escapes += 1
     expansion = {"apache_log": 1.30, "csv2json": 2.05, "iso_datetime_to_json": 4.35, "thousand_sep": 1.40}[a.program]
     out = torch.empty(int(n_local * expansion) + (1 << 20), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -261,7 +274,19 @@ def main():
     want = oracle.run(blob, base)
     parts = workloads.tiled_parts(a.program, want, n_global // len(base))
     my_off = totals["off"] if use_dist else 0
-    ok = workloads.check_tiled_on_device(out[:olen], my_off, parts)
+    if n_escapes:
+        # the input is no longer the tiled chunk: the reference is the general engine's output on the same device buffer (that engine is
+        # checked against the oracle byte for byte by the tests and by every run of this script without --escapes)
+        from kleenexlang_amd import host as khost
+        ref_prog = Program(blob, config=khost.config_from_env(delayed_form=1))
+        ref = torch.empty_like(out)
+        rlen = ref_prog.run_device(t.data_ptr(), n_local, ref.data_ptr(), ref.numel(), stream)
+        torch.cuda.synchronize()
+        ok = rlen == olen and bool(torch.equal(out[:olen], ref[:rlen]))
+        del ref
+        ref_prog.close()
+    else:
+        ok = workloads.check_tiled_on_device(out[:olen], my_off, parts)
     checked = olen
     total_out = totals["out"] if use_dist else olen
     if dist is not None:
@@ -269,7 +294,7 @@ def main():
         okt = agg[:1].clone(); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         cnt = agg[1:].clone(); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         ok, checked = bool(int(okt.item())), int(cnt.item())
-    ok = bool(ok) and total_out == workloads.tiled_total(parts) and checked == total_out
+    ok = bool(ok) and (n_escapes > 0 or total_out == workloads.tiled_total(parts)) and checked == total_out
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -341,6 +366,8 @@ def main():
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
             "clocks": {"before": clocks_before, "after": clocks_after, "source": "rocm-smi -d 0 --showclocks --showpower --showperflevel --json"},
             "output_checked_bit_exact": ok, "output_bytes_checked": checked,
+            "escaped_quotes_injected": n_escapes, "checked_against": ("general engine on the same input" if n_escapes else "CPU oracle (tiled)"),
+            "delayed_form_state_after": df_state,
         }
         if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.program, base, 1 << 30)

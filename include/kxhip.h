@@ -103,6 +103,8 @@ typedef struct kx_config {
 #define KX_OFF_PAIR 2u       /* load: no two-symbol table for k_forward                                                 [KX_NO_PAIR] */
 #define KX_OFF_CMPX 4u       /* load: constants of at most 16 bytes are not stored by the v_cmpx sequences              [KX_NO_CMPX] */
 #define KX_OFF_COOP 8u       /* run:  k_forward without cooperative line loads                                          [KX_NO_COOP] */
+#define KX_OFF_SLOW 16u      /* load: no exact slow path in the delayed form's forward pass: a context that the delay does not decide
+                                sends the whole shard to the general engine, as in round 5                              [KX_NO_SLOW] */
 #define KX_FORCE_BIG 1u      /* load: tables stay in global memory whatever their size (the BIG instances; tests)     [KX_FORCE_BIG] */
 #define KX_FORCE_TBLMODE 2u  /* load: per-entry symbol-table ids even where one table would do (tests)            [KX_FORCE_TBLMODE] */
 #define KX_FORCE_ACT_SEQ 4u  /* run:  the action post-pass on one wave                                                  [KX_ACT_SEQ] */

@@ -41,6 +41,7 @@ static kx_config configFromEnv() {
   if (getenv("KX_NO_PAIR")) c.disable |= KX_OFF_PAIR;
   if (getenv("KX_NO_CMPX")) c.disable |= KX_OFF_CMPX;
   if (getenv("KX_NO_COOP")) c.disable |= KX_OFF_COOP;
+  if (getenv("KX_NO_SLOW")) c.disable |= KX_OFF_SLOW;
   if (getenv("KX_FORCE_BIG")) c.force |= KX_FORCE_BIG;
   if (getenv("KX_FORCE_TBLMODE")) c.force |= KX_FORCE_TBLMODE;
   if (getenv("KX_ACT_SEQ")) c.force |= KX_FORCE_ACT_SEQ;

@@ -71,7 +71,7 @@ class KxConfig(ctypes.Structure):
                [("reserved", ctypes.c_uint32 * 4)]
 
 
-KX_OFF_DIRECT, KX_OFF_PAIR, KX_OFF_CMPX, KX_OFF_COOP = 1, 2, 4, 8
+KX_OFF_DIRECT, KX_OFF_PAIR, KX_OFF_CMPX, KX_OFF_COOP, KX_OFF_SLOW = 1, 2, 4, 8, 16
 KX_FORCE_BIG, KX_FORCE_TBLMODE, KX_FORCE_ACT_SEQ, KX_FORCE_SAME_DEVICE = 1, 2, 4, 8
 
 
@@ -96,7 +96,8 @@ def config_from_env(env=None, **fields):
         c.merge_window = int(env["KX_DF_J"]) + 1
     c.inline_consts = tri("KX_INL")
     c.job_stride = tri("KX_JL") if "KX_JL" in env else (1 if "KX_JL_AUTO_OFF" in env else 0)
-    for name, bit in (("KX_NO_DIRECT", KX_OFF_DIRECT), ("KX_NO_PAIR", KX_OFF_PAIR), ("KX_NO_CMPX", KX_OFF_CMPX), ("KX_NO_COOP", KX_OFF_COOP)):
+    for name, bit in (("KX_NO_DIRECT", KX_OFF_DIRECT), ("KX_NO_PAIR", KX_OFF_PAIR), ("KX_NO_CMPX", KX_OFF_CMPX), ("KX_NO_COOP", KX_OFF_COOP),
+                      ("KX_NO_SLOW", KX_OFF_SLOW)):
         if name in env:
             c.disable |= bit
     for name, bit in (("KX_FORCE_BIG", KX_FORCE_BIG), ("KX_FORCE_TBLMODE", KX_FORCE_TBLMODE), ("KX_ACT_SEQ", KX_FORCE_ACT_SEQ),

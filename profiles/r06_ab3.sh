@@ -17,3 +17,5 @@ ARGS="--program apache_log --escapes 100" run esc100_noslow KX_NO_SLOW=1 KX_DF_B
 ARGS="--program csv2json" run csv X=1
 ARGS="--program iso_datetime_to_json" run iso X=1
 cat $OUT
+KX_DEBUG=1 python bench.py --program apache_log --escapes 100 --steps 2 --warmup 1 --no-cpu 2>&1 >/dev/null | grep "slow path" | sort | uniq -c | head -5 >> $OUT
+cat $OUT

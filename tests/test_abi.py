@@ -157,3 +157,34 @@ def test_big_table_programs_pass_validation():
     assert 256 + (info["nstates"] + 1) * info["nclasses"] * 4 > 256 * 1024
     with pytest.raises(host.EngineError, match="outside engine limits"):
         host.validate_blob(blob)
+
+
+def test_kx_config_mirrors_the_header_and_the_library_reads_no_switch_from_the_environment():
+    """Round 6: the engine's switches are fields of kx_config.  (1) The ctypes mirror has the header's fields in the
+    header's order; (2) the library's sources call getenv only for KX_DEBUG / KX_FD_TRACE / KX_WINDOW_BYTES / KX_READ_THREADS;
+    (3) the old variable names map onto the struct (host.config_from_env, the test binding's twin of kxrun.cpp's configFromEnv);
+    (4) load-time fields act on the host-only table builder: the delayed form can be switched off, its delay and window pinned."""
+    from kleenexlang_amd import compile_file, host
+    txt = open(os.path.join(INC, "kxhip.h")).read()
+    body = re.search(r"typedef struct kx_config \{(.*?)\} kx_config;", txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:uint32_t|uint64_t)\s+([a-z_0-9]+)(?:\[\d+\])?\s*;", body)
+    assert fields == [f[0] for f in host.KxConfig._fields_], (fields, [f[0] for f in host.KxConfig._fields_])
+    eng = os.path.join(build.CSRC, "engine")
+    seen = set()
+    for name in ("kx_engine.hip", "kx_dfkernels.inc", "kx_delayed.h", "kx_sharded.cpp"):
+        seen |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(eng, name)).read()))
+    assert seen <= {"KX_DEBUG", "KX_FD_TRACE", "KX_WINDOW_BYTES", "KX_READ_THREADS"}, seen
+    c = host.config_from_env({"KX_DF": "0", "KX_DF_K": "2", "KX_DF_J": "3", "KX_INL": "1", "KX_JL": "0", "KX_NO_PAIR": "1", "KX_FORCE_BIG": "1",
+                              "KX_EMIT_WAVES": "8", "KX_EMIT_HALF": "0", "KX_DEBUG_FLAGS": "64", "KX_ACT_CHUNK": "2048", "KX_NO_SLOW": "1"})
+    assert (c.delayed_form, c.delay, c.merge_window, c.inline_consts, c.job_stride, c.disable, c.force, c.emit_waves, c.emit_half, c.debug_flags,
+            c.act_chunk) == (1, 2, 4, 2, 1, host.KX_OFF_PAIR | host.KX_OFF_SLOW, host.KX_FORCE_BIG, 8, 1, 64, 2048)
+    blob = compile_file("apache_log")
+    info, _ = host.df_describe(blob, with_image=False, cfg=host.KxConfig())
+    assert info.available == 1 and info.delay == 2 and info.merge_window >= 1            # defaults: the engine picks delay and window
+    info, _ = host.df_describe(blob, with_image=False, cfg=host.config_from_env({}, delayed_form=1))
+    assert info.available == 0 and b"switched off" in info.reason
+    info, _ = host.df_describe(blob, with_image=False, cfg=host.config_from_env({}, delay=2, merge_window=1))
+    assert info.available == 1 and info.merge_window == 0
+    info, _ = host.df_describe(blob, with_image=False, cfg=host.config_from_env({}, delay=2, merge_window=7))
+    assert info.merge_window == 6

@@ -391,10 +391,10 @@ def test_engine_runs_the_delayed_form_and_agrees_with_the_general_engine(prog, s
         want = expect(blob, data)
         for K in (1, 2):
             got, state = _run(blob, data, KX_DF_K=K)
-            # (apache_log's synthetic lines need two symbols after a field's closing quote: at K = 1 every line holds undecided contexts.
-            #  The slow path resolves them — the output is exact — but it carries more than an eighth of the input: the stage gives
-            #  the form up for what follows, 3)
-            assert got == want and state == (3 if prog == "apache_log" and K == 1 and n > 100 else 1), (prog, n, K, state)
+            # (apache_log's synthetic lines need two symbols after a field's closing quote: at K = 1 every line holds undecided contexts —
+            #  in every segment: the slow path is not even armed, the shard falls back and the stage gives the form up, 3; the two
+            #  segments of the small input only make it back off, 2)
+            assert got == want and state == ((3 if n > 5000 else 2) if prog == "apache_log" and K == 1 and n > 100 else 1), (prog, n, K, state)
         got, state = _run(blob, data, KX_DF=0)
         assert got == want and state == 0
 
@@ -869,7 +869,7 @@ def test_undecided_contexts_are_resolved_by_the_lane_that_meets_them():
                 # (dense contexts — 1 line in 17, every second line: the run stays exact; where more than an eighth of the input went
                 #  through the slow path the stage takes the general engine for what follows, 3)
                 st_ = p.stage_delayed_form(0)
-                assert st_ == 1 if every > 100 else st_ in (1, 3), (every, seg, st_, "the shard fell back")
+                assert st_ == 1 if every > 100 else st_ in (1, 2, 3), (every, seg, st_, "the shard fell back")
             finally:
                 p.close()
     # the last line holds the undecided context: the stretch runs to the end of the input, where the final state's leaf decides

@@ -679,6 +679,30 @@ class _Lanes:
             live = [x for x in M2 if x is not None]
             M, q, t = M2, nq, t + 1
             qs[t] = q
+            if len(set(live)) != 1 and (t - a) % 64 == 0 and t + 64 <= end and self.sos(q) != 0xFFFF:
+                # output equivalence at a piece boundary: the (at most 4) live leaves write the same on every open step
+                lv = [l for l, x in enumerate(M) if x is not None]
+                if 0 < len(lv) <= 4:
+                    cur, same = list(lv), True
+                    for u in range(t - 1, prev - 1, -1):
+                        es = [int(st.back[rows[u], c_]) for c_ in cur]
+                        if len({e >> 8 for e in es}) != 1:
+                            same = False
+                            break
+                        cur = [e & 0xFF for e in es]
+                    if same and pend_kinds[0] is None:
+                        for j in range(K):
+                            ks = self.pend(i0, j)[1]
+                            if len({(ks[0] if len(ks) == 1 else ks[c_]) for c_ in cur}) != 1:
+                                same = False
+                    if same:
+                        la = back_to(prev, t, lv[0])
+                        if pend_kinds[0] is None:
+                            for j in range(K):
+                                ks = self.pend(i0, j)[1]
+                                pend_kinds[j] = ks[0] if len(ks) == 1 else ks[la]
+                        mode, e_out = 1, t
+                        break
             if len(set(live)) != 1:
                 continue
             anchor_known(live[0])

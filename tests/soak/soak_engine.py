@@ -7,7 +7,7 @@ from kleenexlang_amd import MatchError, Program, CompileError
 from oracle import oracle
 
 STAR = False
-t0 = time.time(); n = bad = 0; acc = 0; outb = 0; dfs = [0, 0, 0]   # runs by what the stage ran on: general / delayed form / fell back
+t0 = time.time(); n = bad = 0; acc = 0; outb = 0; dfs = [0, 0, 0, 0]   # runs by the stage's state afterwards: no delayed form / on it / backing off after a fall-back / given up
 for seed in range(int(os.environ.get("SOAK_LO", 300)), int(os.environ.get("SOAK_HI", 700))):
     src = randprog.program(seed)
     if STAR:   # make the whole program repeatable so that long accepted inputs exist: main := (old main "|")* with old main renamed

@@ -244,10 +244,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (rocm-smi is a subprocess of about a second: sampled BEFORE the warm-up — between warm-up and the timed steps it would hand the
+    #  first timed step an idle device at its low clock)
+    clocks_before = gpu_clocks() if rank == 0 else None
     for _ in range(a.warmup):
         step()
     fence()
-    clocks_before = gpu_clocks() if rank == 0 else None
     kern = {}
     step_ms = []          # wall time of every step (a step blocks until its output is complete: no extra synchronisation)
     totals["boundary_ms"] = 0.0
@@ -331,7 +333,8 @@ def main():
             "metric": "input GB/s + % HBM-read roofline, apache_log.kex over 10 GiB synthetic log",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_step, 3), "ms_per_step_median": round(sorted(step_ms)[len(step_ms) // 2], 3),
-            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)], "ms_of_each_step": [round(x, 3) for x in step_ms[:64]],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s.kex, %.2f GiB synthetic %s per GPU (seeded 32 MiB chunk replicated, "
                                    "shards cut mid-line), input and output resident in HBM" % (a.program, n_local / 2**30, shape),
@@ -364,7 +367,7 @@ def main():
                                             "GBps": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9, 2) if kern[dom] > 0 else None,
                                             "frac_of_hbm_peak": round(alg[dom] * n_local / (kern[dom] / 1e3) / 1e9 / HBM_PEAK_GBPS, 5) if kern[dom] > 0 else None},
             "kernels_ms": {k: round(v, 4) for k, v in kern.items()},
-            "clocks": {"before": clocks_before, "after": clocks_after, "source": "rocm-smi -d 0 --showclocks --showpower --showperflevel --json"},
+            "clocks": {"before_warmup": clocks_before, "after": clocks_after, "source": "rocm-smi -d 0 --showclocks --showpower --showperflevel --json"},
             "output_checked_bit_exact": ok, "output_bytes_checked": checked,
             "escaped_quotes_injected": n_escapes, "checked_against": ("general engine on the same input" if n_escapes else "CPU oracle (tiled)"),
             "delayed_form_state_after": df_state,
